@@ -1,0 +1,747 @@
+// brisk_capi.hip -- host side of libbrisk_hip.so: the C-ABI of include/brisk_hip.h.
+// Memory management, batching and kernel sequencing; all arithmetic of the path
+// is in brisk_kernels.hip.  There is deliberately NO CPU fallback: without a
+// gfx950 device brisk_hip_create fails with BRISK_HIP_ENODEVICE.
+#include "brisk_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/brisk_hip.h"
+
+namespace {
+
+enum Slot { S_PACK, S_SYNTH, S_COUNT, S_SCAN, S_HIST, S_PSUM, S_TOUCHED, S_SCATTER, S_INSERT, S_QUERY, S_ENUM, S_LOOKUP, S_NSLOTS };
+const char* const kSlotNames[S_NSLOTS] = {"k_pack_ascii", "k_synth", "k_count_kmers", "k_scan", "k_part_hist", "k_psum", "k_touched_need",
+                                          "k_scatter", "k_insert", "k_query", "k_enumerate", "k_lookup"};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct PendingEvent {
+    int slot;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct brisk_hip_index {
+    BriskParams P{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    u64 n_parts = 0, n_buckets = 0;
+    u64 max_batch_reads = 0;
+
+    double* d_coef = nullptr;
+    // the index
+    u64 arena_cap = 0;
+    u64 arena_used_host = 0;
+    IndexDev ix{};
+    // scratch
+    DevBuf staging, parted, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
+    unsigned long long* d_hist = nullptr;  // n_parts + 1
+    u32* d_off = nullptr;                  // n_parts + 1
+    u32* d_cur32 = nullptr;                // n_parts
+    u32* d_touched = nullptr;              // n_parts
+    u32* d_block_sums = nullptr;
+    u32 n_scan_blocks = 0;
+    unsigned long long* d_small = nullptr;  // [0] n_rec [1] overflow(u32) [2] n_touched(u32) [3] need [4] kmers bound
+    unsigned long long* h_small = nullptr;  // pinned mirror
+    u64 nb_skmers = 0;
+    std::vector<u32> h_dir_cnt;  // enumeration snapshot
+    bool dir_snapshot_valid = false;
+    // profiling
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    uint64_t prof_launches[S_NSLOTS] = {};
+    double prof_ms[S_NSLOTS] = {};
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+            return e_ == hipErrorOutOfMemory ? BRISK_HIP_ENOMEM : BRISK_HIP_EHIP;                       \
+        }                                                                                               \
+    } while (0)
+
+int fail(brisk_hip_index* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+int ensure(brisk_hip_index* h, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return BRISK_HIP_OK;
+    if (b.p) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(h, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return BRISK_HIP_OK;
+}
+
+struct ProfScope {
+    brisk_hip_index* h;
+    int slot;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(brisk_hip_index* h_, int slot_) : h(h_), slot(slot_) {
+        if (h->profiling) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (a) {
+            hipEventRecord(b, h->stream);
+            h->pending.push_back({slot, a, b});
+        }
+    }
+};
+
+inline u32 nblocks(u64 n, u32 per) { return (u32)((n + per - 1) / per); }
+
+int launch_check(brisk_hip_index* h, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, BRISK_HIP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return BRISK_HIP_OK;
+}
+
+// arena growth: offsets are bump-allocated, so the used prefix moves verbatim
+int ensure_arena(brisk_hip_index* h, u64 need_entries) {
+    if (h->arena_used_host + need_entries <= h->arena_cap) return BRISK_HIP_OK;
+    u64 ncap = std::max<u64>(h->arena_cap * 2, h->arena_used_host + need_entries);
+    ncap = std::max<u64>(ncap, 1u << 16);
+    u64* nk = nullptr;
+    uint8_t* nc = nullptr;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMalloc((void**)&nk, ncap * 16));
+    hipError_t e = hipMalloc((void**)&nc, ncap);
+    if (e != hipSuccess) {
+        hipFree(nk);
+        return fail(h, BRISK_HIP_ENOMEM, "arena growth: out of device memory");
+    }
+    if (h->arena_used_host) {
+        HIPCHK(h, hipMemcpyAsync(nk, h->ix.keys, h->arena_used_host * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(nc, h->ix.counts, h->arena_used_host, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (h->ix.keys) hipFree(h->ix.keys);
+    if (h->ix.counts) hipFree(h->ix.counts);
+    h->ix.keys = nk;
+    h->ix.counts = nc;
+    h->arena_cap = ncap;
+    return BRISK_HIP_OK;
+}
+
+// exclusive prefix of the record histogram -> d_off (n_parts+1), d_cur32 seeded
+int prefix_partitions(brisk_hip_index* h, u64 n_bins) {
+    ProfScope ps(h, S_PSUM);
+    const u32 nb = nblocks(n_bins, 256 * SCAN_ITEMS);
+    hipLaunchKernelGGL(k_psum_block, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums);
+    hipLaunchKernelGGL(k_psum_top, dim3(1), dim3(1024), 0, h->stream, h->d_block_sums, nb);
+    hipLaunchKernelGGL(k_psum_apply, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums, h->d_off, h->d_cur32);
+    return launch_check(h, "prefix_partitions");
+}
+
+// records (unordered, all owned by this index) -> index.  If have_hist, d_hist
+// already holds this batch's per-partition histogram (the scan filled it).
+int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist) {
+    if (n_rec == 0) return BRISK_HIP_OK;
+    if (n_rec >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
+    const BriskParams& P = h->P;
+    int rc;
+    if (!have_hist) {
+        HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+        ProfScope ps(h, S_HIST);
+        hipLaunchKernelGGL(k_part_hist, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_hist);
+        if ((rc = launch_check(h, "k_part_hist"))) return rc;
+    }
+    if ((rc = prefix_partitions(h, h->n_parts))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 16, h->stream));
+    {
+        ProfScope ps(h, S_TOUCHED);
+        hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
+                           (u32*)(h->d_small + 2));
+    }
+    if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
+    {
+        ProfScope ps(h, S_SCATTER);
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_cur32, (u64*)h->parted.p, 0,
+                           (const u32*)nullptr, (u32*)nullptr);
+        if ((rc = launch_check(h, "k_scatter"))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const u32 n_touched = (u32)h->h_small[2];
+    if (n_touched == 0) return BRISK_HIP_OK;
+    {
+        ProfScope ps(h, S_TOUCHED);
+        hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_touched, n_touched, h->ix.dir_cnt,
+                           h->ix.dir_cap, h->d_small + 3);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 3, h->d_small + 3, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->arena_used_host = h->h_small[5];
+    if ((rc = ensure_arena(h, h->h_small[3]))) return rc;
+    {
+        ProfScope ps(h, S_INSERT);
+        hipLaunchKernelGGL(k_insert, dim3(n_touched), dim3(INSERT_BLOCK), 0, h->stream, P, (const u64*)h->parted.p, h->d_off, h->d_hist,
+                           h->d_touched, h->ix);
+        if ((rc = launch_check(h, "k_insert"))) return rc;
+    }
+    h->nb_skmers += n_rec;
+    h->dir_snapshot_valid = false;
+    return BRISK_HIP_OK;
+}
+
+// scan reads -> records in d_rec (cap records).  n_rec_out on host after a sync.
+int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, u64* d_rec, u64 cap, bool with_hist,
+              bool query_mode, u32* d_tags, u64* n_rec_out) {
+    if (with_hist) HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
+    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags};
+    {
+        ProfScope ps(h, S_SCAN);
+        hipLaunchKernelGGL(k_scan, dim3(nblocks(n_reads, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_reads,
+                           h->d_coef, out, query_mode ? 1 : 0);
+        int rc;
+        if ((rc = launch_check(h, "k_scan"))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_rec_out = h->h_small[0];
+    if ((u32)h->h_small[1]) return BRISK_HIP_ECAPACITY;
+    return BRISK_HIP_OK;
+}
+
+int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out) {
+    HIPCHK(h, hipMemsetAsync(h->d_small + 4, 0, 8, h->stream));
+    {
+        ProfScope ps(h, S_COUNT);
+        const u32 grid = std::min<u32>(nblocks(n_reads, 256), 4096);
+        hipLaunchKernelGGL(k_count_kmers, dim3(grid ? grid : 1), dim3(256), 0, h->stream, d_starts, n_reads, h->P.k, h->d_small + 4);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->d_small + 4, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = h->h_small[4];
+    return BRISK_HIP_OK;
+}
+
+// scan a batch into the staging buffer, retrying once with the exact bound
+int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool with_hist, bool query_mode,
+                    u64* n_rec_out) {
+    int rc;
+    u64 bound = 0;
+    if ((rc = count_kmers(h, d_starts, n_reads, &bound))) return rc;
+    if (bound == 0) {
+        *n_rec_out = 0;
+        return BRISK_HIP_OK;
+    }
+    u64 cap = std::min<u64>(bound, n_reads * 8 + 4096);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = ensure(h, h->staging, cap * h->P.stride * 8))) return rc;
+        u32* tags = nullptr;
+        if (query_mode) {
+            if ((rc = ensure(h, h->tags_a, cap * 4))) return rc;
+            tags = (u32*)h->tags_a.p;
+        }
+        rc = scan_impl(h, d_packed, d_starts, n_reads, (u64*)h->staging.p, cap, with_hist, query_mode, tags, n_rec_out);
+        if (rc != BRISK_HIP_ECAPACITY) return rc;
+        cap = bound;
+    }
+    return fail(h, BRISK_HIP_EHIP, "scan overflowed its exact bound");
+}
+
+int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads) {
+    for (u64 r0 = 0; r0 < n_reads; r0 += h->max_batch_reads) {
+        const u64 nb = std::min<u64>(h->max_batch_reads, n_reads - r0);
+        u64 n_rec = 0;
+        int rc;
+        if ((rc = scan_to_staging(h, d_packed, d_starts + r0, nb, true, false, &n_rec))) return rc;
+        if ((rc = insert_records_impl(h, (const u64*)h->staging.p, n_rec, true))) return rc;
+    }
+    return BRISK_HIP_OK;
+}
+
+int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, unsigned long long* d_sums) {
+    // d_sums[n_reads] must be zeroed by the caller
+    const BriskParams& P = h->P;
+    u64 n_rec = 0;
+    int rc;
+    if ((rc = scan_to_staging(h, d_packed, d_starts, n_reads, true, true, &n_rec))) return rc;
+    if (n_rec == 0) return BRISK_HIP_OK;
+    if ((rc = prefix_partitions(h, h->n_parts))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
+                       (u32*)(h->d_small + 2));
+    if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
+    if ((rc = ensure(h, h->tags_b, n_rec * 4))) return rc;
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, (const u64*)h->staging.p, n_rec, h->d_cur32,
+                       (u64*)h->parted.p, 0, (const u32*)h->tags_a.p, (u32*)h->tags_b.p);
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const u32 n_touched = (u32)h->h_small[2];
+    if (n_touched == 0) return BRISK_HIP_OK;
+    {
+        ProfScope ps(h, S_QUERY);
+        hipLaunchKernelGGL(k_query, dim3(n_touched), dim3(INSERT_BLOCK), 0, h->stream, P, (const u64*)h->parted.p, (const u32*)h->tags_b.p,
+                           h->d_off, h->d_touched, h->ix, d_sums);
+    }
+    return launch_check(h, "k_query");
+}
+
+// host ASCII reads -> device packed stream + starts, in pieces of at most max_bases
+template <class F>
+int for_each_host_batch(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads, F&& body) {
+    const u64 max_bases = 1ull << 30;
+    std::vector<u64> local;
+    for (u64 r0 = 0; r0 < n_reads;) {
+        u64 r1 = r0;
+        while (r1 < n_reads && r1 - r0 < h->max_batch_reads && (r1 == r0 || offsets[r1 + 1] - offsets[r0] <= max_bases)) r1++;
+        const u64 nb = offsets[r1] - offsets[r0];
+        const u64 nr = r1 - r0;
+        int rc;
+        const u64 n_words = (nb + 15) / 16;
+        if ((rc = ensure(h, h->bases_tmp, nb + 16))) return rc;
+        if ((rc = ensure(h, h->packed_tmp, (n_words + 4) * 4))) return rc;
+        if ((rc = ensure(h, h->starts_tmp, (nr + 1) * 8))) return rc;
+        local.resize(nr + 1);
+        for (u64 i = 0; i <= nr; i++) local[i] = offsets[r0 + i] - offsets[r0];
+        if (nb) HIPCHK(h, hipMemcpyAsync(h->bases_tmp.p, bases + offsets[r0], nb, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->starts_tmp.p, local.data(), (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync((char*)h->packed_tmp.p + n_words * 4, 0, 16, h->stream));
+        if (n_words) {
+            ProfScope ps(h, S_PACK);
+            hipLaunchKernelGGL(k_pack_ascii, dim3(nblocks(n_words, 256)), dim3(256), 0, h->stream, (const uint8_t*)h->bases_tmp.p, nb,
+                               (u32*)h->packed_tmp.p, n_words);
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // `local` is reused
+        if ((rc = body(r0, nr))) return rc;
+        r0 = r1;
+    }
+    return BRISK_HIP_OK;
+}
+
+int drain_profile(brisk_hip_index* h) {
+    if (h->pending.empty()) return BRISK_HIP_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& pe : h->pending) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, pe.a, pe.b);
+        h->prof_ms[pe.slot] += ms;
+        h->prof_launches[pe.slot]++;
+        hipEventDestroy(pe.a);
+        hipEventDestroy(pe.b);
+    }
+    h->pending.clear();
+    return BRISK_HIP_OK;
+}
+
+void free_all(brisk_hip_index* h) {
+    auto fr = [](void* p) { if (p) hipFree(p); };
+    for (DevBuf* b : {&h->staging, &h->parted, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+                      &h->lookup_buf})
+        fr(b->p);
+    fr(h->d_coef);
+    fr(h->ix.keys);
+    fr(h->ix.counts);
+    fr(h->ix.dir_off);
+    fr(h->ix.dir_cnt);
+    fr(h->ix.dir_cap);
+    fr(h->ix.cursor);
+    fr(h->ix.bucket_bits);
+    fr(h->ix.stats);
+    fr(h->d_hist);
+    fr(h->d_off);
+    fr(h->d_cur32);
+    fr(h->d_touched);
+    fr(h->d_block_sums);
+    fr(h->d_small);
+    if (h->h_small) hipHostFree(h->h_small);
+    for (auto& pe : h->pending) {
+        hipEventDestroy(pe.a);
+        hipEventDestroy(pe.b);
+    }
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+#define BRISK_API __attribute__((visibility("default")))
+
+BRISK_API uint32_t brisk_hip_abi_version(void) { return BRISK_HIP_ABI_VERSION; }
+
+BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint8_t b, uint32_t data_bytes, const double* coef_table,
+                               const brisk_hip_options* opt) {
+    if (!out) return BRISK_HIP_EINVAL;
+    *out = nullptr;
+    // Parameters contract (parameters.hpp:19-22, Brisk.hpp:50-51, counter.cpp:32)
+    if (!(b >= 1 && b <= m && m < k && k <= 63 && (m & 1) && m <= 31) || !coef_table) return BRISK_HIP_EINVAL;
+    if (data_bytes != 1) return BRISK_HIP_EUNSUPPORTED;
+    brisk_hip_options o{};
+    if (opt) memcpy(&o, opt, std::min<size_t>(opt->struct_size ? opt->struct_size : sizeof(o), sizeof(o)));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || o.device < 0 || o.device >= ndev) return BRISK_HIP_ENODEVICE;
+    brisk_hip_index* h = new (std::nothrow) brisk_hip_index();
+    if (!h) return BRISK_HIP_ENOMEM;
+
+    BriskParams& P = h->P;
+    P.k = k; P.m = m; P.b = b;
+    P.w = k - m;
+    P.suff_reduc = (m - b + 1) / 2;
+    P.kb = k - b;
+    P.nw = (2 * (2 * k - m - b) + 63) / 64;
+    P.stride = P.nw + 1;
+    P.key_comp_sh = 6;
+    P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(2u * b, 22u);
+    P.shift = 2 * b - P.part_bits;
+    // the entry key [bucket low bits | compacted | idx'] must fit 128 bits
+    while (P.shift + 2 * P.kb + 6 > 128 && P.shift > 0) { P.shift--; P.part_bits++; }
+    if (P.shift + 2 * P.kb + 6 > 128 || P.part_bits > 30) {
+        delete h;
+        return BRISK_HIP_EUNSUPPORTED;
+    }
+    P.n_owners = o.n_owners ? o.n_owners : 1;
+    P.owner_rank = o.owner_rank;
+    if (P.owner_rank >= P.n_owners) { delete h; return BRISK_HIP_EINVAL; }
+    P.m_mask = (1ull << (2 * m)) - 1;
+    P.bucket_mask = (1ull << (2 * b)) - 1;
+    h->n_parts = 1ull << P.part_bits;
+    h->n_buckets = 1ull << (2 * b);
+    h->max_batch_reads = o.max_batch_reads ? o.max_batch_reads : (1ull << 26);
+    h->device = o.device;
+
+    auto init = [&]() -> int {
+        HIPCHK(h, hipSetDevice(h->device));
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(h, BRISK_HIP_ENODEVICE, std::string("not a gfx950 device: ") + prop.gcnArchName);
+        if (o.stream) h->stream = (hipStream_t)o.stream;
+        else { HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+        HIPCHK(h, hipMalloc((void**)&h->d_coef, 128 * sizeof(double)));
+        HIPCHK(h, hipMemsetAsync(h->d_coef, 0, 128 * sizeof(double), h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_coef, coef_table, 4 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const u64 np = h->n_parts;
+        HIPCHK(h, hipMalloc((void**)&h->ix.dir_off, np * 8));
+        HIPCHK(h, hipMalloc((void**)&h->ix.dir_cnt, np * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ix.dir_cap, np * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ix.cursor, 8));
+        HIPCHK(h, hipMalloc((void**)&h->ix.stats, 64));
+        const u64 bit_words = (h->n_buckets + 31) / 32;
+        HIPCHK(h, hipMalloc((void**)&h->ix.bucket_bits, bit_words * 4));
+        HIPCHK(h, hipMemsetAsync(h->ix.dir_off, 0, np * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.dir_cnt, 0, np * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.dir_cap, 0, np * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, bit_words * 4, h->stream));
+        HIPCHK(h, hipMalloc((void**)&h->d_hist, (np + 1) * 8));
+        HIPCHK(h, hipMalloc((void**)&h->d_off, (np + 1) * 4));
+        HIPCHK(h, hipMalloc((void**)&h->d_cur32, np * 4));
+        HIPCHK(h, hipMalloc((void**)&h->d_touched, np * 4));
+        h->n_scan_blocks = nblocks(np, 256 * SCAN_ITEMS);
+        HIPCHK(h, hipMalloc((void**)&h->d_block_sums, (size_t)(h->n_scan_blocks + 1) * 4));
+        HIPCHK(h, hipMalloc((void**)&h->d_small, 64));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_small, 64));
+        HIPCHK(h, hipMemsetAsync(h->d_small, 0, 64, h->stream));
+        if (o.arena_entries) {
+            int rc = ensure_arena(h, o.arena_entries);
+            if (rc) return rc;
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return BRISK_HIP_OK;
+    };
+    int rc = init();
+    if (rc != BRISK_HIP_OK) {
+        fprintf(stderr, "brisk_hip_create: %s\n", h->err.c_str());
+        free_all(h);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_destroy(brisk_hip_index* h) {
+    if (!h) return BRISK_HIP_EINVAL;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return BRISK_HIP_OK;
+}
+
+BRISK_API const char* brisk_hip_last_error(const brisk_hip_index* h) { return h ? h->err.c_str() : "null handle"; }
+
+BRISK_API int brisk_hip_sync(brisk_hip_index* h) {
+    if (!h) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_get_layout(const brisk_hip_index* h, brisk_hip_layout* out) {
+    if (!h || !out) return BRISK_HIP_EINVAL;
+    const BriskParams& P = h->P;
+    out->k = P.k; out->m = P.m; out->b = P.b;
+    out->m_reduc = P.m - P.b;
+    out->compacted_size = P.kb;
+    out->allocated_bytes = (2 * P.k - P.m - P.b + 3) / 4;  // parameters.hpp:31
+    out->record_words = P.stride;
+    out->part_bits = P.part_bits;
+    out->n_owners = P.n_owners;
+    out->owner_rank = P.owner_rank;
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_insert_packed(brisk_hip_index* h, const uint32_t* d_packed, const uint64_t* d_starts, uint64_t n_reads) {
+    if (!h || (n_reads && (!d_packed || !d_starts))) return BRISK_HIP_EINVAL;
+    if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "insert_packed on a sharded index: use scan/route/insert_records");
+    HIPCHK(h, hipSetDevice(h->device));
+    return insert_packed_impl(h, d_packed, d_starts, n_reads);
+}
+
+BRISK_API int brisk_hip_insert_reads(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads) {
+    if (!h || (n_reads && (!bases || !offsets))) return BRISK_HIP_EINVAL;
+    if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "insert_reads on a sharded index: use scan/route/insert_records");
+    HIPCHK(h, hipSetDevice(h->device));
+    return for_each_host_batch(h, bases, offsets, n_reads, [&](u64, u64 nr) {
+        return insert_packed_impl(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, nr);
+    });
+}
+
+BRISK_API int brisk_hip_get_reads(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t* per_read_sum) {
+    if (!h || (n_reads && (!bases || !offsets || !per_read_sum))) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    return for_each_host_batch(h, bases, offsets, n_reads, [&](u64 r0, u64 nr) -> int {
+        int rc;
+        if ((rc = ensure(h, h->sums_tmp, nr * 8))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->sums_tmp.p, 0, nr * 8, h->stream));
+        if ((rc = query_packed_impl(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, nr, (unsigned long long*)h->sums_tmp.p))) return rc;
+        HIPCHK(h, hipMemcpyAsync(per_read_sum + r0, h->sums_tmp.p, nr * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return BRISK_HIP_OK;
+    });
+}
+
+BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, const uint64_t* kmer_hi, const uint8_t* minimizer_idx, uint64_t n,
+                               uint8_t* out_data, uint8_t* out_found) {
+    if (!h || (n && (!kmer_lo || !kmer_hi || !minimizer_idx || !out_data || !out_found))) return BRISK_HIP_EINVAL;
+    if (n == 0) return BRISK_HIP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->lookup_buf, n * 19 + 64))) return rc;
+    char* base = (char*)h->lookup_buf.p;
+    u64* d_lo = (u64*)base;
+    u64* d_hi = (u64*)(base + n * 8);
+    uint8_t* d_idx = (uint8_t*)(base + n * 16);
+    uint8_t* d_data = d_idx + n;
+    uint8_t* d_found = d_data + n;
+    HIPCHK(h, hipMemcpyAsync(d_lo, kmer_lo, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_hi, kmer_hi, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_idx, minimizer_idx, n, hipMemcpyHostToDevice, h->stream));
+    {
+        ProfScope ps(h, S_LOOKUP);
+        hipLaunchKernelGGL(k_lookup, dim3(nblocks(n * 64, 256)), dim3(256), 0, h->stream, h->P, h->ix, d_lo, d_hi, d_idx, n, d_data, d_found);
+        if ((rc = launch_check(h, "k_lookup"))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(out_data, d_data, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out_found, d_found, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_enumerate(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo, uint64_t* out_hi, uint8_t* out_minimizer_idx,
+                                  uint8_t* out_data, uint64_t cap, uint64_t* n_out) {
+    if (!h || !cursor || !n_out || (cap && (!out_lo || !out_hi || !out_minimizer_idx || !out_data))) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_out = 0;
+    if (*cursor == 0 || !h->dir_snapshot_valid) {
+        h->h_dir_cnt.resize(h->n_parts);
+        HIPCHK(h, hipMemcpyAsync(h->h_dir_cnt.data(), h->ix.dir_cnt, h->n_parts * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->dir_snapshot_valid = true;
+    }
+    u64 p = *cursor;
+    while (p < h->n_parts && h->h_dir_cnt[p] == 0) p++;
+    if (p >= h->n_parts) { *cursor = h->n_parts; return BRISK_HIP_OK; }
+    std::vector<u64> base;
+    u64 total = 0, q = p;
+    while (q < h->n_parts && total + h->h_dir_cnt[q] <= cap) {
+        base.push_back(total);
+        total += h->h_dir_cnt[q];
+        q++;
+    }
+    if (q == p) return fail(h, BRISK_HIP_ECAPACITY, "enumerate: cap smaller than one partition");
+    const u64 np = q - p;
+    int rc;
+    if ((rc = ensure(h, h->enum_out, np * 8 + total * 18 + 64))) return rc;
+    char* b0 = (char*)h->enum_out.p;
+    u64* d_base = (u64*)b0;
+    u64* d_lo = (u64*)(b0 + np * 8);
+    u64* d_hi = d_lo + total;
+    uint8_t* d_idx = (uint8_t*)(d_hi + total);
+    uint8_t* d_cnt = d_idx + total;
+    HIPCHK(h, hipMemcpyAsync(d_base, base.data(), np * 8, hipMemcpyHostToDevice, h->stream));
+    if (total) {
+        ProfScope ps(h, S_ENUM);
+        hipLaunchKernelGGL(k_enumerate, dim3((u32)np), dim3(64), 0, h->stream, h->P, h->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt);
+        if ((rc = launch_check(h, "k_enumerate"))) return rc;
+        HIPCHK(h, hipMemcpyAsync(out_lo, d_lo, total * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(out_hi, d_hi, total * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(out_minimizer_idx, d_idx, total, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(out_data, d_cnt, total, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *cursor = q;
+    *n_out = total;
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t* nb_skmers, uint64_t* nb_kmers, uint64_t* memory_bytes,
+                              uint64_t* largest_bucket) {
+    if (!h) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long st[4];
+    HIPCHK(h, hipMemcpyAsync(st, h->ix.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (nb_kmers) *nb_kmers = st[0];
+    if (nb_buckets) *nb_buckets = st[1];
+    if (largest_bucket) *largest_bucket = st[2];
+    if (nb_skmers) *nb_skmers = h->nb_skmers;
+    if (memory_bytes) {
+        u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
+        for (const DevBuf* b : {&h->staging, &h->parted, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
+                                &h->enum_out, &h->lookup_buf})
+            m += b->bytes;
+        *memory_bytes = m;
+    }
+    return BRISK_HIP_OK;
+}
+
+// ---- cut at the super-k-mer boundary ---------------------------------------
+BRISK_API int brisk_hip_scan_bound(brisk_hip_index* h, const uint64_t* d_starts, uint64_t n_reads, uint64_t* bound) {
+    if (!h || !bound || (n_reads && !d_starts)) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    *bound = 0;
+    if (!n_reads) return BRISK_HIP_OK;
+    u64 b = 0;
+    int rc = count_kmers(h, d_starts, n_reads, &b);
+    *bound = b;
+    return rc;
+}
+
+BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed, const uint64_t* d_starts, uint64_t n_reads, uint64_t* d_records,
+                                    uint64_t cap_records, uint64_t* n_records) {
+    if (!h || !n_records || (n_reads && (!d_packed || !d_starts)) || (cap_records && !d_records)) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_records = 0;
+    if (!n_reads) return BRISK_HIP_OK;
+    u64 n = 0;
+    int rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, false, nullptr, &n);
+    *n_records = n;
+    return rc;
+}
+
+BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records, uint64_t* d_out, uint64_t* counts) {
+    if (!h || !counts || (n_records && (!d_records || !d_out))) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const u32 no = h->P.n_owners;
+    for (u32 i = 0; i < no; i++) counts[i] = 0;
+    if (!n_records) return BRISK_HIP_OK;
+    if (n_records >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
+    if (no > h->n_parts) return fail(h, BRISK_HIP_EINVAL, "more owners than partitions");
+    int rc;
+    HIPCHK(h, hipMemsetAsync(h->d_hist, 0, ((u64)no + 1) * 8, h->stream));
+    {
+        ProfScope ps(h, S_HIST);
+        hipLaunchKernelGGL(k_owner_hist, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_hist);
+    }
+    if ((rc = prefix_partitions(h, no))) return rc;
+    {
+        ProfScope ps(h, S_SCATTER);
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_cur32, d_out, 1,
+                           (const u32*)nullptr, (u32*)nullptr);
+        if ((rc = launch_check(h, "k_scatter(owner)"))) return rc;
+    }
+    std::vector<u32> off(no + 1);
+    HIPCHK(h, hipMemcpyAsync(off.data(), h->d_off, ((u64)no + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (u32 i = 0; i < no; i++) counts[i] = off[i + 1] - off[i];
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_insert_records(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records) {
+    if (!h || (n_records && !d_records)) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    return insert_records_impl(h, d_records, n_records, false);
+}
+
+// ---- helpers ------------------------------------------------------------------
+BRISK_API int brisk_hip_pack_ascii(brisk_hip_index* h, const char* d_bases, uint64_t n_bases, uint32_t* d_packed) {
+    if (!h || (n_bases && (!d_bases || !d_packed))) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 n_words = (n_bases + 15) / 16;
+    if (!n_words) return BRISK_HIP_OK;
+    ProfScope ps(h, S_PACK);
+    hipLaunchKernelGGL(k_pack_ascii, dim3(nblocks(n_words, 256)), dim3(256), 0, h->stream, (const uint8_t*)d_bases, n_bases, d_packed, n_words);
+    return launch_check(h, "k_pack_ascii");
+}
+
+BRISK_API int brisk_hip_synth_reads(brisk_hip_index* h, uint64_t genome_len, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                    uint64_t seed_g, uint64_t seed_r, uint32_t* d_packed, uint64_t* d_starts) {
+    if (!h || !d_packed || !d_starts || read_len == 0 || genome_len < read_len) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 n_words = (n_reads * (u64)read_len + 15) / 16;
+    const u64 n_threads = std::max<u64>(n_words, n_reads + 1);
+    ProfScope ps(h, S_SYNTH);
+    hipLaunchKernelGGL(k_synth, dim3(nblocks(n_threads, 256)), dim3(256), 0, h->stream, genome_len, first_read, n_reads, read_len, seed_g, seed_r,
+                       d_packed, n_words, d_starts);
+    return launch_check(h, "k_synth");
+}
+
+// ---- measurement ---------------------------------------------------------------
+BRISK_API int brisk_hip_profile_enable(brisk_hip_index* h, int on) {
+    if (!h) return BRISK_HIP_EINVAL;
+    int rc = drain_profile(h);
+    h->profiling = on != 0;
+    return rc;
+}
+BRISK_API int brisk_hip_profile_reset(brisk_hip_index* h) {
+    if (!h) return BRISK_HIP_EINVAL;
+    int rc = drain_profile(h);
+    for (int i = 0; i < S_NSLOTS; i++) { h->prof_ms[i] = 0; h->prof_launches[i] = 0; }
+    return rc;
+}
+BRISK_API int brisk_hip_profile_read(brisk_hip_index* h, uint32_t* n_slots, const char** names, uint64_t* launches, double* ms) {
+    if (!h || !n_slots) return BRISK_HIP_EINVAL;
+    int rc = drain_profile(h);
+    *n_slots = S_NSLOTS;
+    for (int i = 0; i < S_NSLOTS; i++) {
+        if (names) names[i] = kSlotNames[i];
+        if (launches) launches[i] = h->prof_launches[i];
+        if (ms) ms[i] = h->prof_ms[i];
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,274 @@
+"""ctypes binding of include/brisk_hip.h (one-to-one; no logic)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_LIB_NAME = "libbrisk_hip.so"
+
+STATUS = {0: "OK", 1: "EINVAL", 2: "EUNSUPPORTED", 3: "EHIP", 4: "ENOMEM", 5: "ECAPACITY", 6: "ENODEVICE"}
+ECAPACITY = 5
+
+
+class BriskHipError(RuntimeError):
+    def __init__(self, code: int, msg: str = ""):
+        self.code = code
+        super().__init__(f"brisk_hip: {STATUS.get(code, code)} {msg}".strip())
+
+
+def library_path() -> str:
+    return os.path.join(HERE, _LIB_NAME)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). In-tree output."""
+    out = library_path()
+    srcs = [os.path.join(HERE, "csrc", f) for f in ("brisk_capi.hip", "brisk_kernels.hip", "brisk_device.h")]
+    srcs.append(os.path.join(ROOT, "include", "brisk_hip.h"))
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Wno-unused-value", "-o", out, srcs[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def coef_table(m: int) -> np.ndarray:
+    """DecyclingSet(m) coefficients (reference brisk/Decycling.cpp:7-13), computed on
+    the HOST with libm; the device only ever sees these bits."""
+    unit = 2 * math.pi / m
+    coef = np.zeros(4 * m, dtype=np.float64)
+    for j in range(1, m):
+        s = math.sin(unit * float(j))
+        coef[4 * j + 1] = s
+        coef[4 * j + 2] = 2 * s
+        coef[4 * j + 3] = 3 * s
+    return coef
+
+
+class _Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p), ("part_bits", C.c_uint32),
+                ("owner_rank", C.c_uint32), ("n_owners", C.c_uint32), ("arena_entries", C.c_uint64),
+                ("max_batch_reads", C.c_uint64)]
+
+
+class _Layout(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("k", "m", "b", "m_reduc", "compacted_size", "allocated_bytes", "record_words",
+                                          "part_bits", "n_owners", "owner_rank")]
+
+
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+# every symbol include/brisk_hip.h declares
+SYMBOLS = [
+    "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_last_error", "brisk_hip_sync",
+    "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
+    "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
+    "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_profile_enable",
+    "brisk_hip_profile_read", "brisk_hip_profile_reset",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise BriskHipError(6, f"{path} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+    L = C.CDLL(path)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.brisk_hip_abi_version.restype = u32
+    L.brisk_hip_create.argtypes = [C.POINTER(vp), C.c_uint8, C.c_uint8, C.c_uint8, u32, C.POINTER(C.c_double), C.POINTER(_Options)]
+    L.brisk_hip_destroy.argtypes = [vp]
+    L.brisk_hip_last_error.argtypes = [vp]
+    L.brisk_hip_last_error.restype = C.c_char_p
+    L.brisk_hip_sync.argtypes = [vp]
+    L.brisk_hip_get_layout.argtypes = [vp, C.POINTER(_Layout)]
+    L.brisk_hip_insert_reads.argtypes = [vp, _u8p, _u64p, u64]
+    L.brisk_hip_insert_packed.argtypes = [vp, vp, vp, u64]
+    L.brisk_hip_get_reads.argtypes = [vp, _u8p, _u64p, u64, _u64p]
+    L.brisk_hip_lookup.argtypes = [vp, _u64p, _u64p, _u8p, u64, _u8p, _u8p]
+    L.brisk_hip_enumerate.argtypes = [vp, C.POINTER(u64), _u64p, _u64p, _u8p, _u8p, u64, C.POINTER(u64)]
+    L.brisk_hip_stats.argtypes = [vp] + [C.POINTER(u64)] * 5
+    L.brisk_hip_scan_packed.argtypes = [vp, vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.brisk_hip_scan_bound.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.brisk_hip_route_records.argtypes = [vp, vp, u64, vp, _u64p]
+    L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
+    L.brisk_hip_pack_ascii.argtypes = [vp, vp, u64, vp]
+    L.brisk_hip_synth_reads.argtypes = [vp, u64, u64, u64, u32, u64, u64, vp, vp]
+    L.brisk_hip_profile_enable.argtypes = [vp, i32]
+    L.brisk_hip_profile_read.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.brisk_hip_profile_reset.argtypes = [vp]
+    for s in SYMBOLS:
+        if getattr(L, s).restype is C.c_int:
+            pass
+    _lib = L
+    return L
+
+
+def _pack_reads(seqs) -> Tuple[np.ndarray, np.ndarray]:
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    flat = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(flat), offs
+
+
+class BriskHip:
+    """One index handle.  Methods map one-to-one onto the C-ABI."""
+
+    def __init__(self, k: int, m: int, b: int, device: int = 0, stream: Optional[int] = None, part_bits: int = 0,
+                 owner_rank: int = 0, n_owners: int = 1, arena_entries: int = 0, max_batch_reads: int = 0):
+        self.L = load()
+        self.h = C.c_void_p()
+        self.k, self.m, self.b = k, m, b
+        opt = _Options(C.sizeof(_Options), device, stream, part_bits, owner_rank, n_owners, arena_entries, max_batch_reads)
+        coef = coef_table(m) if 1 <= m <= 31 else np.zeros(4, np.float64)
+        rc = self.L.brisk_hip_create(C.byref(self.h), k, m, b, 1, coef.ctypes.data_as(C.POINTER(C.c_double)), C.byref(opt))
+        if rc:
+            self.h = C.c_void_p()
+            raise BriskHipError(rc, f"create(k={k},m={m},b={b})")
+        lay = _Layout()
+        self._chk(self.L.brisk_hip_get_layout(self.h, C.byref(lay)))
+        self.layout = {n: getattr(lay, n) for n, _ in _Layout._fields_}
+        self.record_words = lay.record_words
+
+    def _chk(self, rc: int):
+        if rc:
+            raise BriskHipError(rc, (self.L.brisk_hip_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.brisk_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- bulk host paths
+    def insert_reads(self, seqs: Sequence) -> None:
+        flat, offs = _pack_reads(seqs)
+        self.insert_flat(flat, offs)
+
+    def insert_flat(self, flat: np.ndarray, offs: np.ndarray) -> None:
+        if len(flat) == 0:
+            flat = np.zeros(1, np.uint8)
+        self._chk(self.L.brisk_hip_insert_reads(self.h, flat, offs, len(offs) - 1))
+
+    def get_reads(self, seqs: Sequence) -> np.ndarray:
+        flat, offs = _pack_reads(seqs)
+        out = np.zeros(len(offs) - 1, np.uint64)
+        if len(flat) == 0:
+            flat = np.zeros(1, np.uint8)
+        self._chk(self.L.brisk_hip_get_reads(self.h, flat, offs, len(offs) - 1, out))
+        return out
+
+    def lookup(self, lo, hi, idx) -> Tuple[np.ndarray, np.ndarray]:
+        lo = np.ascontiguousarray(lo, np.uint64)
+        hi = np.ascontiguousarray(hi, np.uint64)
+        idx = np.ascontiguousarray(idx, np.uint8)
+        n = len(lo)
+        data = np.zeros(max(n, 1), np.uint8)
+        found = np.zeros(max(n, 1), np.uint8)
+        self._chk(self.L.brisk_hip_lookup(self.h, lo, hi, idx, n, data, found))
+        return data[:n], found[:n]
+
+    def enumerate(self, chunk: int = 1 << 20):
+        """All entries: (lo, hi, minimizer_idx, count) arrays, k-mers unhashed."""
+        cur = C.c_uint64(0)
+        n = C.c_uint64(0)
+        los, his, idxs, cnts = [], [], [], []
+        cap = chunk
+        while True:
+            lo = np.zeros(cap, np.uint64)
+            hi = np.zeros(cap, np.uint64)
+            idx = np.zeros(cap, np.uint8)
+            cnt = np.zeros(cap, np.uint8)
+            rc = self.L.brisk_hip_enumerate(self.h, C.byref(cur), lo, hi, idx, cnt, cap, C.byref(n))
+            if rc == ECAPACITY:
+                cap *= 4
+                continue
+            self._chk(rc)
+            if n.value == 0:
+                break
+            los.append(lo[: n.value]); his.append(hi[: n.value]); idxs.append(idx[: n.value]); cnts.append(cnt[: n.value])
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+        return cat(los, np.uint64), cat(his, np.uint64), cat(idxs, np.uint8), cat(cnts, np.uint8)
+
+    def stats(self) -> dict:
+        v = [C.c_uint64() for _ in range(5)]
+        self._chk(self.L.brisk_hip_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("nb_buckets", "nb_skmers", "nb_kmers", "memory_bytes", "largest_bucket"), (x.value for x in v)))
+
+    def sync(self):
+        self._chk(self.L.brisk_hip_sync(self.h))
+
+    # ---- device-buffer paths (pointers are ints: tensor.data_ptr())
+    def insert_packed(self, d_packed: int, d_starts: int, n_reads: int):
+        self._chk(self.L.brisk_hip_insert_packed(self.h, d_packed, d_starts, n_reads))
+
+    def scan_bound(self, d_starts: int, n_reads: int) -> int:
+        out = C.c_uint64()
+        self._chk(self.L.brisk_hip_scan_bound(self.h, d_starts, n_reads, C.byref(out)))
+        return out.value
+
+    def scan_packed(self, d_packed: int, d_starts: int, n_reads: int, d_records: int, cap: int) -> int:
+        out = C.c_uint64()
+        rc = self.L.brisk_hip_scan_packed(self.h, d_packed, d_starts, n_reads, d_records, cap, C.byref(out))
+        if rc == ECAPACITY:
+            raise BriskHipError(rc, f"scan needs {out.value} records, cap {cap}")
+        self._chk(rc)
+        return out.value
+
+    def route_records(self, d_records: int, n: int, d_out: int) -> np.ndarray:
+        counts = np.zeros(max(self.layout["n_owners"], 1), np.uint64)
+        self._chk(self.L.brisk_hip_route_records(self.h, d_records, n, d_out, counts))
+        return counts
+
+    def insert_records(self, d_records: int, n: int):
+        self._chk(self.L.brisk_hip_insert_records(self.h, d_records, n))
+
+    def pack_ascii(self, d_bases: int, n_bases: int, d_packed: int):
+        self._chk(self.L.brisk_hip_pack_ascii(self.h, d_bases, n_bases, d_packed))
+
+    def synth_reads(self, genome_len: int, first_read: int, n_reads: int, read_len: int, d_packed: int, d_starts: int,
+                    seed_g: int = 1, seed_r: int = 2):
+        self._chk(self.L.brisk_hip_synth_reads(self.h, genome_len, first_read, n_reads, read_len, seed_g, seed_r, d_packed, d_starts))
+
+    # ---- measurement
+    def profile_enable(self, on: bool = True):
+        self._chk(self.L.brisk_hip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.brisk_hip_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        n = C.c_uint32()
+        names = (C.c_char_p * 16)()
+        launches = (C.c_uint64 * 16)()
+        ms = (C.c_double * 16)()
+        self._chk(self.L.brisk_hip_profile_read(self.h, C.byref(n), names, launches, ms))
+        return {names[i].decode(): {"launches": launches[i], "ms": ms[i]} for i in range(n.value)}

@@ -1,0 +1,169 @@
+/*
+ * brisk_hip.h -- C-ABI of the MI355X-native Brisk hot path (libbrisk_hip.so).
+ *
+ * The reference has no FFI layer: its boundary is the header-only C++ API
+ * consumed by apps/counter.cpp.  This C-ABI is the boundary
+ * between that host-side C++ (brisk_amd/include/Brisk.hpp, same names as the
+ * reference's) and the HIP kernels.  Plain pointers and sizes only; no C++,
+ * torch or HIP types appear in any signature.  Every entry point returns an
+ * int status (BRISK_HIP_OK == 0), never throws, and is thread-compatible: one
+ * HIP stream per handle, external synchronisation between threads.
+ *
+ * Reference interface each entry point stands in for (file:line under the
+ * reference tree):
+ *   brisk_hip_create            Parameters ctor + Brisk ctor + DenseMenuYo ctor
+ *                               (brisk/parameters.hpp:24-34, brisk/Brisk.hpp:47-52,
+ *                                brisk/DenseMenuYo.hpp:104-138)
+ *   brisk_hip_destroy           Brisk dtor (brisk/Brisk.hpp:57-59)
+ *   brisk_hip_insert_reads      count_sequence loop: SuperKmerEnumerator::next +
+ *                               Brisk::protect_data/insert_superkmer/unprotect_data +
+ *                               the counter update (apps/counter.cpp:231-276,
+ *                               brisk/Kmers.cpp:522-603, brisk/Brisk.hpp:123-161);
+ *                               also the declared-but-undefined
+ *                               Brisk::insert_sequence (brisk/Brisk.hpp:27)
+ *   brisk_hip_get_reads         query_sequence (apps/counter.cpp:281-310) over
+ *                               Brisk::get_superkmer (brisk/Brisk.hpp:102-118) /
+ *                               Brisk::get_sequence (brisk/Brisk.hpp:28)
+ *   brisk_hip_lookup            Brisk::get (brisk/Brisk.hpp:64-69)
+ *   brisk_hip_enumerate         Brisk::next / restart_kmer_enumeration
+ *                               (brisk/Brisk.hpp:166-179, brisk/DenseMenuYo.hpp:476-521)
+ *   brisk_hip_stats             Brisk::stats (brisk/Brisk.hpp:194-197,
+ *                               brisk/DenseMenuYo.hpp:545-568)
+ *   brisk_hip_scan_packed / brisk_hip_route_records / brisk_hip_insert_records
+ *                               the same insert path cut at the super-k-mer
+ *                               boundary (the vector<kmer_full> handed from
+ *                               SuperKmerEnumerator::next to Brisk::insert_superkmer,
+ *                               apps/counter.cpp:242-261) so that records can be
+ *                               exchanged between GPUs (no reference counterpart:
+ *                               the reference is single-process)
+ *   brisk_hip_pack_ascii        nuc2int (brisk/Kmers.cpp:442-444) applied in bulk
+ *   brisk_hip_synth_reads       no reference counterpart (benchmark input,
+ *                               SURVEY.md 8(d))
+ */
+#ifndef BRISK_HIP_H
+#define BRISK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRISK_HIP_ABI_VERSION 1
+
+enum {
+    BRISK_HIP_OK = 0,
+    BRISK_HIP_EINVAL = 1,       /* parameter contract violated (e.g. b > m, m even) */
+    BRISK_HIP_EUNSUPPORTED = 2, /* valid for the reference but outside this library's envelope */
+    BRISK_HIP_EHIP = 3,         /* a HIP runtime call failed; see brisk_hip_last_error */
+    BRISK_HIP_ENOMEM = 4,       /* device or host allocation failed */
+    BRISK_HIP_ECAPACITY = 5,    /* caller-provided output buffer too small */
+    BRISK_HIP_ENODEVICE = 6     /* no usable gfx950 device */
+};
+
+typedef struct brisk_hip_index brisk_hip_index;
+
+typedef struct brisk_hip_options {
+    uint32_t struct_size;       /* sizeof(brisk_hip_options), for ABI growth */
+    int32_t device;             /* HIP device ordinal */
+    void *stream;               /* hipStream_t to run on, NULL: the library creates one */
+    uint32_t part_bits;         /* log2(#partitions); 0: default min(2b, 22) */
+    uint32_t owner_rank;        /* this process' rank among n_owners bucket-range owners */
+    uint32_t n_owners;          /* 0 or 1: this index owns every bucket */
+    uint64_t arena_entries;     /* initial entry capacity of the k-mer arena; 0: grow on demand */
+    uint64_t max_batch_reads;   /* reads per internal scan batch; 0: default */
+} brisk_hip_options;
+
+/* ---- lifetime ----------------------------------------------------------- */
+/* coef_table: the 4*m doubles of DecyclingSet(m) computed on the HOST with libm
+ * (brisk/Decycling.cpp:7-13); the device never evaluates sin().  data_bytes must
+ * be 1 (the counter app's uint8_t DATA). */
+int brisk_hip_create(brisk_hip_index **out, uint8_t k, uint8_t m, uint8_t b, uint32_t data_bytes,
+                     const double *coef_table, const brisk_hip_options *opt);
+int brisk_hip_destroy(brisk_hip_index *h);
+const char *brisk_hip_last_error(const brisk_hip_index *h);
+int brisk_hip_sync(brisk_hip_index *h);
+uint32_t brisk_hip_abi_version(void);
+
+/* derived constants (mirrors brisk/parameters.hpp:24-34) */
+typedef struct brisk_hip_layout {
+    uint32_t k, m, b, m_reduc, compacted_size, allocated_bytes;
+    uint32_t record_words;      /* u64 words per super-k-mer record (incl. header word) */
+    uint32_t part_bits;         /* log2(#partitions) */
+    uint32_t n_owners, owner_rank;
+} brisk_hip_layout;
+int brisk_hip_get_layout(const brisk_hip_index *h, brisk_hip_layout *out);
+
+/* ---- bulk count (DATA = uint8_t counter: first touch = 1, then ++ mod 256) -- */
+/* HOST buffers: `bases` = concatenated sequences, `offsets[n_reads+1]`.  Sequences
+ * must be clean ([ACGTacgt]; the N-splitting of counter.cpp:130-169 is the caller's);
+ * sequences shorter than k are skipped (counter.cpp:233-235). */
+int brisk_hip_insert_reads(brisk_hip_index *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+
+/* DEVICE buffers: 2-bit packed stream (16 nts per u32, first nt in the top bits;
+ * A0 C1 T2 G3) and per-read start offsets in nucleotides, starts[n_reads+1].
+ * d_packed must be readable 8 bytes past the last used word. */
+int brisk_hip_insert_packed(brisk_hip_index *h, const uint32_t *d_packed, const uint64_t *d_starts, uint64_t n_reads);
+
+/* ---- bulk query ---------------------------------------------------------- */
+/* per_read_sum[r] = sum of the counts of the read's k-mers that are present,
+ * with query_sequence's quirk: enumeration of a read stops at the first
+ * super-k-mer after the first whose minimizer value is 0 (counter.cpp:304-306). */
+int brisk_hip_get_reads(brisk_hip_index *h, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                        uint64_t *per_read_sum);
+
+/* point lookups of UNHASHED (kmer_s, minimizer_idx) pairs, as Brisk::get takes them.
+ * HOST arrays; out_found[i] in {0,1}; out_data[i] valid when found. */
+int brisk_hip_lookup(brisk_hip_index *h, const uint64_t *kmer_lo, const uint64_t *kmer_hi, const uint8_t *minimizer_idx,
+                     uint64_t n, uint8_t *out_data, uint8_t *out_found);
+
+/* ---- enumeration --------------------------------------------------------- */
+/* Walks the index in ascending partition (bucket-range) order, storage order
+ * inside one.  *cursor = 0 restarts (restart_kmer_enumeration); the call
+ * returns up to cap entries into HOST arrays (k-mers unhashed, as Brisk::next
+ * yields them), advances *cursor, and sets *n_out; *n_out == 0 means done. */
+int brisk_hip_enumerate(brisk_hip_index *h, uint64_t *cursor, uint64_t *out_lo, uint64_t *out_hi,
+                        uint8_t *out_minimizer_idx, uint8_t *out_data, uint64_t cap, uint64_t *n_out);
+
+/* nb_buckets and nb_kmers are exact and order independent; nb_skmers and
+ * largest_bucket depend on insertion order in the reference and are reported
+ * here as: super-k-mer records received, largest partition (entries). */
+int brisk_hip_stats(brisk_hip_index *h, uint64_t *nb_buckets, uint64_t *nb_skmers, uint64_t *nb_kmers,
+                    uint64_t *memory_bytes, uint64_t *largest_bucket);
+
+/* ---- the path cut at the super-k-mer boundary (multi-GPU) ----------------- */
+/* scan: d_records receives up to cap_records records of record_words u64 each;
+ * *n_records (HOST) receives the count.  BRISK_HIP_ECAPACITY if cap is too small
+ * (nothing is inserted by a scan, so the call can simply be repeated). */
+int brisk_hip_scan_packed(brisk_hip_index *h, const uint32_t *d_packed, const uint64_t *d_starts, uint64_t n_reads,
+                          uint64_t *d_records, uint64_t cap_records, uint64_t *n_records);
+/* upper bound on the records a scan of these reads can emit (HOST result) */
+int brisk_hip_scan_bound(brisk_hip_index *h, const uint64_t *d_starts, uint64_t n_reads, uint64_t *bound);
+/* route: reorder records so that each owner's records are contiguous, owner 0
+ * first; counts[n_owners] (HOST) receives records per owner.  d_out may not alias d_in. */
+int brisk_hip_route_records(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records,
+                            uint64_t *d_out, uint64_t *counts);
+/* insert records whose buckets this index owns */
+int brisk_hip_insert_records(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records);
+
+/* ---- helpers on device buffers -------------------------------------------- */
+int brisk_hip_pack_ascii(brisk_hip_index *h, const char *d_bases, uint64_t n_bases, uint32_t *d_packed);
+/* synthetic reads of SURVEY.md 8(d), written packed; d_starts[n_reads+1] */
+int brisk_hip_synth_reads(brisk_hip_index *h, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                          uint32_t read_len, uint64_t seed_g, uint64_t seed_r,
+                          uint32_t *d_packed, uint64_t *d_starts);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* With profiling on, every kernel launch is bracketed by HIP events on the
+ * handle's stream.  brisk_hip_profile_read returns, per kernel slot, launches
+ * and total milliseconds since the last reset. */
+#define BRISK_HIP_PROFILE_SLOTS 16
+int brisk_hip_profile_enable(brisk_hip_index *h, int on);
+int brisk_hip_profile_read(brisk_hip_index *h, uint32_t *n_slots, const char **names, uint64_t *launches, double *ms);
+int brisk_hip_profile_reset(brisk_hip_index *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRISK_HIP_H */

@@ -1,0 +1,269 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle and the golden
+fixtures.  Everything here is integer/byte work: the bar is bit-exact."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import brisk_amd
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a device"
+    assert brisk_amd.library_path()
+    return brisk_amd
+
+
+def md5_lines(lines):
+    return hashlib.md5("".join("{} idx={} {}\n".format(*l.split()) for l in lines).encode()).hexdigest()
+
+
+def gpu_count(B, seqs, k, m, b, batches=1, **kw):
+    with B.BriskHip(k, m, b, **kw) as ix:
+        step = max(1, (len(seqs) + batches - 1) // batches)
+        for i in range(0, len(seqs), step):
+            ix.insert_reads(seqs[i:i + step])
+        st = ix.stats()
+        lines = oracle.multiset_lines(*ix.enumerate(), k)
+    return lines, st["nb_kmers"], st["nb_buckets"]
+
+
+def _seqs(name):
+    return oracle.fasta_sequences(load_golden(name))
+
+
+CONFIGS = [(31, 11, 4), (63, 21, 14), (31, 13, 12), (31, 15, 14), (63, 21, 9), (31, 11, 11), (31, 11, 10)]
+
+
+def test_reference_fixtures_against_golden(B):
+    """config #1 and friends: the reference's own data files, golden md5s from the reference."""
+    for e in load_golden("multisets.json"):
+        if e["input"] not in ("test.fa", "debug_test.fa"):
+            continue
+        lines, nk, nb = gpu_count(B, _seqs(e["input"]), e["k"], e["m"], e["b"])
+        assert (nk, nb) == (e["nb_kmers"], e["nb_buckets"]), e
+        assert sum(int(l.split()[2]) for l in lines) == e["sum_counts"]
+        assert md5_lines(lines) == e["md5"], (e["input"], e["k"], e["m"], e["b"])
+
+
+def test_full_multiset_fixture(B):
+    for k, m, b in ((31, 11, 4), (63, 21, 14)):
+        want = load_golden(f"multiset_test_k{k}m{m}b{b}.txt.gz").split("\n")[:-1]
+        assert gpu_count(B, _seqs("test.fa"), k, m, b)[0] == want
+
+
+def test_synthetic_goldens(B, O):
+    for e in load_golden("multisets.json"):
+        if not e["input"].startswith("synth:"):
+            continue
+        kv = dict(p.split("=") for p in e["input"][6:].split(","))
+        seqs = [bytes(r) for r in O.synth_reads(int(kv["G"]), 0, int(kv["n"]))]
+        lines, nk, nb = gpu_count(B, seqs, e["k"], e["m"], e["b"])
+        assert (nk, nb) == (e["nb_kmers"], e["nb_buckets"])
+        assert md5_lines(lines) == e["md5"]
+        with B.BriskHip(e["k"], e["m"], e["b"]) as ix:
+            ix.insert_reads(seqs)
+            assert [int(v) for v in ix.get_reads(seqs[:50])] == e["query_sums_first50"]
+
+
+def _random_reads(rng, n, glen, L=150):
+    genome = "".join(rng.choice("ACGT") for _ in range(glen))
+    out = []
+    for _ in range(n):
+        p = rng.randrange(0, glen - L)
+        s = genome[p:p + L]
+        if rng.random() < 0.5:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        out.append(s)
+    return out
+
+
+SPECIAL = ["A" * 150, "C" * 150, "G" * 150, "T" * 150, "AC" * 75, "ACG" * 50, "ACGT" * 40, "T" * 149 + "A",
+           "A" * 70 + "ACGTTGCA" * 10, "acgt" * 40, "ACGTTGCATGCA" * 13]
+
+
+@pytest.mark.parametrize("k,m,b", CONFIGS + [(33, 11, 7), (47, 15, 10), (21, 7, 3), (63, 31, 12), (41, 21, 5), (63, 21, 4)])
+def test_random_and_degenerate_reads_vs_oracle(B, O, k, m, b):
+    rng = random.Random(k * 1000 + m * 10 + b)
+    reads = _random_reads(rng, 500, 5000) + SPECIAL
+    reads += ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 400))) for _ in range(40)]  # ragged, some < k
+    reads += ["", "A", "ACGT" * 5]
+    want = O.count(reads, k, m, b)
+    got = gpu_count(B, reads, k, m, b)
+    assert got[1:] == want[1:]
+    assert got[0] == want[0]
+
+
+def test_insert_is_incremental_and_order_independent(B, O):
+    rng = random.Random(5)
+    reads = _random_reads(rng, 1500, 8000) + SPECIAL
+    for k, m, b in ((63, 21, 14), (31, 11, 11)):
+        want = O.count(reads, k, m, b)
+        assert gpu_count(B, reads, k, m, b, batches=7) == want
+        shuffled = reads[:]
+        rng.shuffle(shuffled)
+        assert gpu_count(B, shuffled, k, m, b, batches=3) == want
+        assert gpu_count(B, reads, k, m, b, max_batch_reads=100) == want
+
+
+def test_counts_wrap_mod_256(B, O):
+    s = "ACGTTGCATGCCGATAGCTAGCTAGGATCGATCGGCTAGCTAGCTAGGCTAGCCATAGACCAGATTTACAGGATACCCAGGGTAAACCA"
+    for k, m, b in ((31, 11, 4), (63, 21, 14)):
+        assert gpu_count(B, [s] * 700, k, m, b, batches=3) == O.count([s] * 700, k, m, b)
+
+
+def test_hot_partition_multi_chunk(B, O):
+    """One partition receiving far more instances than one LDS chunk holds."""
+    rng = random.Random(11)
+    base = _random_reads(rng, 30, 400)
+    reads = base * 200 + ["A" * 150] * 300
+    for k, m, b, pb in ((31, 11, 4, 0), (63, 21, 9, 2), (31, 11, 11, 1)):
+        assert gpu_count(B, reads, k, m, b, part_bits=pb) == O.count(reads, k, m, b)
+
+
+def test_lookup_and_get(B, O):
+    rng = random.Random(21)
+    reads = _random_reads(rng, 600, 6000) + SPECIAL
+    for k, m, b in ((31, 11, 4), (63, 21, 14)):
+        flat, offs = oracle.pack_reads(reads)
+        h = O.index_new(k, m, b)
+        O.index_insert_reads(h, flat, offs)
+        lo, hi, idx, cnt = O.index_dump(h)
+        with B.BriskHip(k, m, b) as ix:
+            ix.insert_reads(reads)
+            data, found = ix.lookup(lo, hi, idx)
+            assert found.all() and np.array_equal(data, cnt)
+            # absent: flip a nucleotide far from the minimizer / wrong idx
+            lo2 = lo ^ np.uint64(1)
+            data2, found2 = ix.lookup(lo2, hi, idx)
+            want2 = np.array([O.index_get(h, int(a), int(c), int(i)) for a, c, i in zip(lo2[:500], hi[:500], idx[:500])])
+            assert np.array_equal(found2[:500].astype(bool), want2 >= 0)
+            assert np.array_equal(data2[:500][want2 >= 0], want2[want2 >= 0].astype(np.uint8))
+            # bulk per-read query incl. the minimizer==0 break (counter.cpp:304-306)
+            q = reads[:200] + SPECIAL + _random_reads(rng, 100, 6000)
+            qf, qo = oracle.pack_reads(q)
+            assert np.array_equal(ix.get_reads(q), O.index_query_reads(h, qf, qo))
+        O.index_free(h)
+
+
+def test_scan_records_match_oracle_records(B, O):
+    """The scan kernel's output, record by record (the super-k-mer boundary of the path)."""
+    import torch
+    rng = random.Random(31)
+    reads = _random_reads(rng, 300, 4000) + SPECIAL
+    for k, m, b in ((31, 11, 4), (31, 11, 11), (63, 21, 14), (47, 15, 10)):
+        h = O.index_new(k, m, b)
+        want = []
+        for s in reads:
+            c, bucket, n, idx0 = O.records(h, s, k, m, b)
+            for i in range(len(n)):
+                want.append(tuple(int(x) for x in c[i]) + (int(bucket[i]), int(n[i]), int(idx0[i])))
+        O.index_free(h)
+        flat, offs = oracle.pack_reads(reads)
+        with B.BriskHip(k, m, b) as ix:
+            d_bases = torch.from_numpy(flat).cuda()
+            d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+            d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+            torch.cuda.synchronize()
+            ix.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+            bound = ix.scan_bound(d_starts.data_ptr(), len(reads))
+            assert bound == sum(max(0, len(s) - k + 1) for s in reads)
+            W = ix.record_words
+            d_rec = torch.zeros(bound * W, dtype=torch.int64, device="cuda")
+            n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), len(reads), d_rec.data_ptr(), bound)
+            ix.sync()
+            rec = d_rec.cpu().numpy().view(np.uint64)[: n_rec * W].reshape(n_rec, W)
+        got = [tuple(int(x) for x in r[: W - 1]) + (int(r[W - 1]) & 0xffffffff, (int(r[W - 1]) >> 32) & 0xff, (int(r[W - 1]) >> 40) & 0xff)
+               for r in rec]
+        assert sorted(got) == sorted(want)
+
+
+def test_bucket_range_sharding_two_owners(B, O):
+    """scan -> route by owner -> insert on the owner: union of the shards == oracle."""
+    import torch
+    rng = random.Random(41)
+    reads = _random_reads(rng, 800, 6000) + SPECIAL
+    for k, m, b in ((63, 21, 14), (31, 11, 4)):
+        want = O.count(reads, k, m, b)
+        flat, offs = oracle.pack_reads(reads)
+        owners = [B.BriskHip(k, m, b, owner_rank=r, n_owners=2) for r in range(2)]
+        d_bases = torch.from_numpy(flat).cuda()
+        d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+        d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        ix0 = owners[0]
+        ix0.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        ix0.sync()
+        W = ix0.record_words
+        # each "rank" scans half of the reads
+        half = len(reads) // 2
+        inbox = [[], []]
+        for r, (lo, hi) in enumerate(((0, half), (half, len(reads)))):
+            ix = owners[r]
+            st = d_starts[lo:hi + 1].contiguous()
+            bound = ix.scan_bound(st.data_ptr(), hi - lo)
+            d_rec = torch.zeros(max(bound, 1) * W, dtype=torch.int64, device="cuda")
+            d_out = torch.zeros_like(d_rec)
+            torch.cuda.synchronize()
+            n_rec = ix.scan_packed(d_packed.data_ptr(), st.data_ptr(), hi - lo, d_rec.data_ptr(), bound)
+            counts = ix.route_records(d_rec.data_ptr(), n_rec, d_out.data_ptr())
+            ix.sync()
+            assert int(counts.sum()) == n_rec
+            o0 = int(counts[0])
+            inbox[0].append(d_out[: o0 * W].clone())
+            inbox[1].append(d_out[o0 * W: n_rec * W].clone())
+        lines, nk, nb = [], 0, 0
+        for r in range(2):
+            recv = torch.cat(inbox[r])
+            torch.cuda.synchronize()
+            owners[r].insert_records(recv.data_ptr(), recv.numel() // W)
+            st = owners[r].stats()
+            nk += st["nb_kmers"]
+            nb += st["nb_buckets"]
+            lines += oracle.multiset_lines(*owners[r].enumerate(), k)
+        for ix in owners:
+            ix.close()
+        assert (sorted(lines), nk, nb) == want
+
+
+def test_device_synth_generator_matches_oracle(B, O):
+    import torch
+    k, m, b = 63, 21, 14
+    G, n, L = 30000, 3000, 150
+    seqs = [bytes(r) for r in O.synth_reads(G, 100, n)]
+    want = O.count(seqs, k, m, b)
+    with B.BriskHip(k, m, b) as ix:
+        d_packed = torch.zeros((n * L + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+        d_starts = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ix.synth_reads(G, 100, n, L, d_packed.data_ptr(), d_starts.data_ptr())
+        ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n)
+        st = ix.stats()
+        got = oracle.multiset_lines(*ix.enumerate(), k)
+    assert (got, st["nb_kmers"], st["nb_buckets"]) == want
+
+
+def test_parameter_contract(B):
+    for k, m, b in ((31, 11, 14), (31, 12, 4), (31, 31, 4), (64, 21, 14), (31, 11, 0), (63, 33, 4)):
+        with pytest.raises(B.BriskHipError) as e:
+            B.BriskHip(k, m, b)
+        assert e.value.code == 1
+    with pytest.raises(B.BriskHipError) as e:  # key does not fit 128 bits: outside this library's envelope
+        B.BriskHip(63, 21, 1)
+    assert e.value.code == 2
+
+
+def test_empty_inputs(B):
+    with B.BriskHip(31, 11, 4) as ix:
+        ix.insert_reads([])
+        ix.insert_reads(["", "ACGT"])
+        assert ix.stats()["nb_kmers"] == 0
+        assert len(ix.enumerate()[0]) == 0
+        assert list(ix.get_reads(["ACGT", ""])) == [0, 0]
