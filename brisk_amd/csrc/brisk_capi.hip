@@ -491,6 +491,22 @@ BRISK_API int brisk_hip_destroy(brisk_hip_index* h) {
     return BRISK_HIP_OK;
 }
 
+BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
+    if (!h) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 np = h->n_parts;
+    HIPCHK(h, hipMemsetAsync(h->ix.dir_off, 0, np * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.dir_cnt, 0, np * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.dir_cap, 0, np * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, ((h->n_buckets + 31) / 32) * 4, h->stream));
+    h->arena_used_host = 0;
+    h->nb_skmers = 0;
+    h->dir_snapshot_valid = false;
+    return BRISK_HIP_OK;
+}
+
 BRISK_API const char* brisk_hip_last_error(const brisk_hip_index* h) { return h ? h->err.c_str() : "null handle"; }
 
 BRISK_API int brisk_hip_sync(brisk_hip_index* h) {

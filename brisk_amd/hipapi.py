@@ -71,7 +71,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 # every symbol include/brisk_hip.h declares
 SYMBOLS = [
-    "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_last_error", "brisk_hip_sync",
+    "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
     "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_profile_enable",
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     L.brisk_hip_abi_version.restype = u32
     L.brisk_hip_create.argtypes = [C.POINTER(vp), C.c_uint8, C.c_uint8, C.c_uint8, u32, C.POINTER(C.c_double), C.POINTER(_Options)]
     L.brisk_hip_destroy.argtypes = [vp]
+    L.brisk_hip_clear.argtypes = [vp]
     L.brisk_hip_last_error.argtypes = [vp]
     L.brisk_hip_last_error.restype = C.c_char_p
     L.brisk_hip_sync.argtypes = [vp]
@@ -222,6 +223,9 @@ class BriskHip:
         v = [C.c_uint64() for _ in range(5)]
         self._chk(self.L.brisk_hip_stats(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("nb_buckets", "nb_skmers", "nb_kmers", "memory_bytes", "largest_bucket"), (x.value for x in v)))
+
+    def clear(self):
+        self._chk(self.L.brisk_hip_clear(self.h))
 
     def sync(self):
         self._chk(self.L.brisk_hip_sync(self.h))

@@ -15,6 +15,9 @@
  *                               (brisk/parameters.hpp:24-34, brisk/Brisk.hpp:47-52,
  *                                brisk/DenseMenuYo.hpp:104-138)
  *   brisk_hip_destroy           Brisk dtor (brisk/Brisk.hpp:57-59)
+ *   brisk_hip_clear             `delete menu; menu = new DenseMenuYo` (what Brisk::reallocate does
+ *                               to start over, brisk/Brisk.hpp:220-222): an empty index that keeps
+ *                               its device memory reserved
  *   brisk_hip_insert_reads      count_sequence loop: SuperKmerEnumerator::next +
  *                               Brisk::protect_data/insert_superkmer/unprotect_data +
  *                               the counter update (apps/counter.cpp:231-276,
@@ -82,6 +85,8 @@ typedef struct brisk_hip_options {
 int brisk_hip_create(brisk_hip_index **out, uint8_t k, uint8_t m, uint8_t b, uint32_t data_bytes,
                      const double *coef_table, const brisk_hip_options *opt);
 int brisk_hip_destroy(brisk_hip_index *h);
+/* back to the empty index; device memory stays reserved for the next job */
+int brisk_hip_clear(brisk_hip_index *h);
 const char *brisk_hip_last_error(const brisk_hip_index *h);
 int brisk_hip_sync(brisk_hip_index *h);
 uint32_t brisk_hip_abi_version(void);
