@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--coverage", type=float, default=15.0)
+    ap.add_argument("--part-bits", type=int, default=0, help="log2(#partitions); 0: library default")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="after timing, check a property of the result")
@@ -99,7 +100,7 @@ def main():
 
     # one handle for the whole run: every step starts from brisk_hip_clear(), i.e. an
     # empty index whose device memory is already reserved (the allocator, not the path)
-    ix = brisk_amd.BriskHip(k, m, b, device=local_rank, stream=sptr, owner_rank=rank, n_owners=N)
+    ix = brisk_amd.BriskHip(k, m, b, device=local_rank, stream=sptr, owner_rank=rank, n_owners=N, part_bits=args.part_bits)
 
     def one_job(profile):
         """empty index + the whole hot path over this rank's reads"""

@@ -46,7 +46,7 @@ struct brisk_hip_index {
     u64 arena_used_host = 0;
     IndexDev ix{};
     // scratch
-    DevBuf staging, parted, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
+    DevBuf staging, parted, desc, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
     u32* d_cur32 = nullptr;                // n_parts
@@ -192,18 +192,20 @@ int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     if (n_touched == 0) return BRISK_HIP_OK;
     {
         ProfScope ps(h, S_TOUCHED);
-        hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_touched, n_touched, h->ix.dir_cnt,
-                           h->ix.dir_cap, h->d_small + 3);
+        if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
+        hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched,
+                           h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3);
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 3, h->d_small + 3, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->arena_used_host = h->h_small[5];
-    if ((rc = ensure_arena(h, h->h_small[3]))) return rc;
+    if ((rc = ensure_arena(h, h->h_small[3] + (u64)INSERT_SLOTS * ARENA_CHUNK))) return rc;
     {
         ProfScope ps(h, S_INSERT);
-        hipLaunchKernelGGL(k_insert, dim3(n_touched), dim3(INSERT_BLOCK), 0, h->stream, P, (const u64*)h->parted.p, h->d_off, h->d_hist,
-                           h->d_touched, h->ix);
+        HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
+        hipLaunchKernelGGL(k_insert, dim3(std::min<u32>((n_touched + WI_BATCH - 1) / WI_BATCH, INSERT_SLOTS)), dim3(64), 0, h->stream, P,
+                           (const u64*)h->parted.p, (const PartDesc*)h->desc.p, n_touched, h->ix, (u32*)(h->d_small + 6));
         if ((rc = launch_check(h, "k_insert"))) return rc;
     }
     h->nb_skmers += n_rec;
@@ -301,8 +303,8 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     if (n_touched == 0) return BRISK_HIP_OK;
     {
         ProfScope ps(h, S_QUERY);
-        hipLaunchKernelGGL(k_query, dim3(n_touched), dim3(INSERT_BLOCK), 0, h->stream, P, (const u64*)h->parted.p, (const u32*)h->tags_b.p,
-                           h->d_off, h->d_touched, h->ix, d_sums);
+        hipLaunchKernelGGL(k_query, dim3(std::min<u32>(n_touched, 4096u)), dim3(INSERT_BLOCK), 0, h->stream, P, (const u64*)h->parted.p,
+                           (const u32*)h->tags_b.p, h->d_off, h->d_touched, n_touched, h->ix, d_sums);
     }
     return launch_check(h, "k_query");
 }
@@ -356,18 +358,18 @@ int drain_profile(brisk_hip_index* h) {
 
 void free_all(brisk_hip_index* h) {
     auto fr = [](void* p) { if (p) hipFree(p); };
-    for (DevBuf* b : {&h->staging, &h->parted, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+    for (DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);
     fr(h->ix.keys);
     fr(h->ix.counts);
-    fr(h->ix.dir_off);
-    fr(h->ix.dir_cnt);
-    fr(h->ix.dir_cap);
+    fr(h->ix.dir);
     fr(h->ix.cursor);
     fr(h->ix.bucket_bits);
     fr(h->ix.stats);
+    fr(h->ix.slot_cur);
+    fr(h->ix.slot_end);
     fr(h->d_hist);
     fr(h->d_off);
     fr(h->d_cur32);
@@ -413,7 +415,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     P.nw = (2 * (2 * k - m - b) + 63) / 64;
     P.stride = P.nw + 1;
     P.key_comp_sh = 6;
-    P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(2u * b, 22u);
+    P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(2u * b, 24u);
     P.shift = 2 * b - P.part_bits;
     // the entry key [bucket low bits | compacted | idx'] must fit 128 bits
     while (P.shift + 2 * P.kb + 6 > 128 && P.shift > 0) { P.shift--; P.part_bits++; }
@@ -442,16 +444,16 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMemsetAsync(h->d_coef, 0, 128 * sizeof(double), h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_coef, coef_table, 4 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
         const u64 np = h->n_parts;
-        HIPCHK(h, hipMalloc((void**)&h->ix.dir_off, np * 8));
-        HIPCHK(h, hipMalloc((void**)&h->ix.dir_cnt, np * 4));
-        HIPCHK(h, hipMalloc((void**)&h->ix.dir_cap, np * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ix.dir, np * sizeof(DirEnt)));
         HIPCHK(h, hipMalloc((void**)&h->ix.cursor, 8));
         HIPCHK(h, hipMalloc((void**)&h->ix.stats, 64));
+        HIPCHK(h, hipMalloc((void**)&h->ix.slot_cur, INSERT_SLOTS * 8));
+        HIPCHK(h, hipMalloc((void**)&h->ix.slot_end, INSERT_SLOTS * 8));
+        HIPCHK(h, hipMemsetAsync(h->ix.slot_cur, 0, INSERT_SLOTS * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.slot_end, 0, INSERT_SLOTS * 8, h->stream));
         const u64 bit_words = (h->n_buckets + 31) / 32;
         HIPCHK(h, hipMalloc((void**)&h->ix.bucket_bits, bit_words * 4));
-        HIPCHK(h, hipMemsetAsync(h->ix.dir_off, 0, np * 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->ix.dir_cnt, 0, np * 4, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->ix.dir_cap, 0, np * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ix.dir, 0, np * sizeof(DirEnt), h->stream));
         HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
         HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, bit_words * 4, h->stream));
@@ -495,11 +497,11 @@ BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     const u64 np = h->n_parts;
-    HIPCHK(h, hipMemsetAsync(h->ix.dir_off, 0, np * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->ix.dir_cnt, 0, np * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->ix.dir_cap, 0, np * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.dir, 0, np * sizeof(DirEnt), h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.slot_cur, 0, INSERT_SLOTS * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.slot_end, 0, INSERT_SLOTS * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, ((h->n_buckets + 31) / 32) * 4, h->stream));
     h->arena_used_host = 0;
     h->nb_skmers = 0;
@@ -593,7 +595,9 @@ BRISK_API int brisk_hip_enumerate(brisk_hip_index* h, uint64_t* cursor, uint64_t
     *n_out = 0;
     if (*cursor == 0 || !h->dir_snapshot_valid) {
         h->h_dir_cnt.resize(h->n_parts);
-        HIPCHK(h, hipMemcpyAsync(h->h_dir_cnt.data(), h->ix.dir_cnt, h->n_parts * 4, hipMemcpyDeviceToHost, h->stream));
+        // d_cur32 is per-batch scratch, free between batches
+        hipLaunchKernelGGL(k_dir_counts, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->ix.dir, h->n_parts, h->d_cur32);
+        HIPCHK(h, hipMemcpyAsync(h->h_dir_cnt.data(), h->d_cur32, h->n_parts * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->dir_snapshot_valid = true;
     }
@@ -637,6 +641,14 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
                               uint64_t* largest_bucket) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    // nb_kmers / nb_buckets / largest are reductions over the directory and the bucket bitmap
+    const u64 bit_words = (h->n_buckets + 31) / 32;
+    if (h->P.shift > 6) {  // partitions wider than 64 buckets: rebuild the bitmap from the entries
+        HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, bit_words * 4, h->stream));
+        hipLaunchKernelGGL(k_bucket_bits, dim3((u32)std::min<u64>(h->n_parts, 4096)), dim3(256), 0, h->stream, h->P, h->ix, (u32)h->n_parts);
+    }
+    HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 24, h->stream));
+    hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, h->stream, h->ix.dir, h->n_parts, h->ix.bucket_bits, bit_words, h->ix.stats);
     unsigned long long st[4];
     HIPCHK(h, hipMemcpyAsync(st, h->ix.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -646,7 +658,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (nb_skmers) *nb_skmers = h->nb_skmers;
     if (memory_bytes) {
         u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
-        for (const DevBuf* b : {&h->staging, &h->parted, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
+        for (const DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
                                 &h->enum_out, &h->lookup_buf})
             m += b->bytes;
         *memory_bytes = m;

@@ -15,7 +15,7 @@
 #define INSERT_BLOCK 256
 #define INS_TABLE 2048      // LDS hash slots per partition chunk
 #define INS_MAX_INST 1280   // k-mer instances per chunk (load <= 0.625)
-#define INS_MAX_REC 256     // records per chunk
+#define INS_MAX_REC 128     // records per chunk
 #define EMPTY_SLOT 0xffffffffu
 #define MATCHED_BIT 0x80000000u
 
@@ -369,17 +369,39 @@ __global__ void __launch_bounds__(256) k_touched(const unsigned long long* __res
     if (hit) list[base + __popcll(bal & ((1ull << lane) - 1))] = (u32)p;
 }
 
-// arena space the insert of this batch may need (all instances new), per touched partition
+// Per touched partition: a 32-byte work descriptor for k_insert (so that its
+// persistent workgroups fetch ONE predictable line per partition instead of
+// chasing touched[] -> part_off[] -> dir_*[]), and the arena space the batch may
+// need if every instance were new.
+struct DirEnt {                  // one 16-byte directory line per partition
+    unsigned long long off;      // first entry of the partition's slice
+    u32 cnt, cap;                // entries in use / slice capacity
+};
+struct PartDesc {
+    u32 part, r_begin, n_rec, n_inst, n_exist, cap;
+    unsigned long long off;
+};
 __device__ __forceinline__ u32 grow_cap(u32 n) { return n + (n >> 2) + 8; }
-__global__ void __launch_bounds__(256) k_need(const unsigned long long* __restrict__ hist, const u32* __restrict__ list, u32 n_list,
-                                              const u32* __restrict__ dir_cnt, const u32* __restrict__ dir_cap, unsigned long long* out) {
+__global__ void __launch_bounds__(256) k_need(const unsigned long long* __restrict__ hist, const u32* __restrict__ part_off,
+                                              const u32* __restrict__ list, u32 n_list, const DirEnt* __restrict__ dir,
+                                              PartDesc* __restrict__ desc, unsigned long long* out) {
     __shared__ unsigned long long s_sum[4];
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long need = 0;
     if (i < n_list) {
         const u32 p = list[i];
-        const u32 tot = dir_cnt[p] + (u32)(hist[p] >> 32);
-        if (tot > dir_cap[p]) need = grow_cap(tot);
+        PartDesc d;
+        d.part = p;
+        d.r_begin = part_off[p];
+        d.n_rec = part_off[p + 1] - d.r_begin;
+        d.n_inst = (u32)(hist[p] >> 32);
+        const DirEnt de = dir[p];
+        d.n_exist = de.cnt;
+        d.cap = de.cap;
+        d.off = de.off;
+        desc[i] = d;
+        const u32 tot = d.n_exist + d.n_inst;
+        if (tot > d.cap) need = grow_cap(tot);
     }
     for (int o = 32; o > 0; o >>= 1) need += __shfl_down(need, o, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = need;
@@ -419,295 +441,512 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
 }
 
 // ===========================================================================
-// k_insert: one workgroup per touched partition.
-//   1. the chunk's k-mer instances are de-duplicated in an LDS table whose slots
-//      hold (record, j) of the first instance and a multiplicity;
+// k_insert: persistent workgroups, each walking a strided share of the touched
+// partitions.  Per partition (per chunk of at most INS_MAX_INST k-mer instances):
+//   0. every k-mer instance of the chunk's records is expanded to its 128-bit
+//      entry key in LDS (one wave per record, one lane per k-mer);
+//   1. the instances are de-duplicated in an LDS table whose slots hold the index
+//      of the first instance and a multiplicity;
 //   2. the partition's existing entries stream through the table: a hit adds the
 //      multiplicity to the entry's count (uint8_t, wraps; counter.cpp:264-268);
 //   3. unmatched table entries are appended as new entries (count = multiplicity).
-// Storage per partition: keys[] (u128) and counts[] (u8) in a bump-allocated arena;
-// a partition that outgrows its slice moves to a fresh one.
+// Storage per partition: keys[] (u128) and counts[] (u8) in a bump-allocated arena.
+// A partition that outgrows its slice moves to a fresh one taken from the
+// workgroup's private arena chunk, so the global cursor sees one atomic per
+// ARENA_CHUNK entries.  nb_kmers / nb_buckets are reductions done at stats() time:
+// the kernel has no same-address global atomics on its data path.
+#define ARENA_CHUNK 32768u
+#define INSERT_SLOTS 2560u   // persistent waves == private allocator slots (256 CUs x 10)
 struct IndexDev {
     u64* keys;                   // 2 u64 per entry
     uint8_t* counts;
-    unsigned long long* dir_off; // per partition: first entry
-    u32* dir_cnt;
-    u32* dir_cap;
-    unsigned long long* cursor;  // arena entries in use
+    DirEnt* dir;
+    unsigned long long* cursor;  // arena entries handed out
     u32* bucket_bits;            // one bit per bucket id
-    unsigned long long* stats;   // [0] nb_kmers [1] nb_buckets [2] largest partition [3] garbage entries
+    unsigned long long* stats;   // [3] garbage entries (abandoned slices)
+    unsigned long long* slot_cur;  // per persistent workgroup: private chunk [cur, end)
+    unsigned long long* slot_end;
 };
 
-__device__ __forceinline__ u128x chunk_key(const BriskParams& P, const u64* s_rec, u32 rec, u32 j) {
-    const u64* c = s_rec + rec * P.stride;
-    const u64 hdr = c[P.nw];
-    return make_key(P, hdr_bucket(hdr), record_kmer(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+// k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
+// independent stream of partitions, so a CU keeps ~10 of them in flight and their
+// LDS / HBM latencies overlap.  Sized for partitions of a few hundred k-mer
+// instances (part_bits = 24 at b = 14: 16 buckets per partition).
+#define WI_MAX_INST 512     // k-mer instances per chunk
+#define WI_TABLE 1024       // LDS table slots (load <= 0.5)
+#define WI_MAX_REC 64       // records per chunk: one per lane
+#define WI_CNT_SHIFT 10     // table word = [MATCHED | multiplicity (21 b) | instance (10 b)]
+#define WI_IDX_MASK 0x3ffu
+#define wave_sync() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+__device__ __forceinline__ u32 table_size_for(u32 ninst) {
+    u32 t = 128;
+    while (t < 2 * ninst && t < WI_TABLE) t <<= 1;
+    return t;
 }
 
-__global__ void __launch_bounds__(INSERT_BLOCK) k_insert(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ part_off,
-                                                         const unsigned long long* __restrict__ hist,
-                                                         const u32* __restrict__ touched, IndexDev ix) {
-    __shared__ u64 s_rec[INS_MAX_REC * 5];
-    __shared__ u32 s_tab[INS_TABLE];
-    __shared__ u32 s_cnt[INS_TABLE];
-    __shared__ u32 s_pref[INS_MAX_REC + 1];
-    __shared__ u32 s_wave[INSERT_BLOCK / 64];
-    __shared__ u32 s_nrec, s_ninst, s_nnew;
-    __shared__ unsigned long long s_off;
-    __shared__ u32 s_cap;
+// record words of the calling lane's record (lane r < n loads record first+r), 5 words at most
+struct RecRegs {
+    u64 w0, w1, w2, w3, w4;
+};
+__device__ __forceinline__ RecRegs load_rec_regs(const BriskParams& P, const u64* __restrict__ rec, u32 first, u32 n, u32 lane) {
+    RecRegs r{0, 0, 0, 0, 0};
+    if (lane < n) {
+        const u64* c = rec + (u64)(first + lane) * P.stride;
+        r.w0 = c[0];
+        r.w1 = c[1];
+        if (P.stride > 2) r.w2 = c[2];
+        if (P.stride > 3) r.w3 = c[3];
+        if (P.stride > 4) r.w4 = c[4];
+    }
+    return r;
+}
+__device__ __forceinline__ u32 wave_incl_scan(u32 x, u32 lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = __shfl_up(x, o, 64);
+        if ((int)lane >= o) x += y;
+    }
+    return x;
+}
+__device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1ull << lane) - 1; }
 
-    const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const u32 part = touched[blockIdx.x];
-    const u32 r_begin = part_off[part], r_end = part_off[part + 1];
-    u32 n_exist = ix.dir_cnt[part];
-    const u32 n_exist0 = n_exist;
-    u32 inst_left = (u32)(hist[part] >> 32);  // instances not yet processed: bounds the final size
-    if (tid == 0) {
-        s_off = ix.dir_off[part];
-        s_cap = ix.dir_cap[part];
+#define WI_NI (WI_MAX_INST / 64)   // instances per lane
+#define WI_TS (WI_TABLE / 64)      // table words per lane
+
+// k-mer j of record words in LDS, branch-free (every load is unconditional so that the
+// unrolled instances of a lane keep their LDS reads in flight together)
+__device__ __forceinline__ u128x record_kmer_lds(const BriskParams& P, const u64* c, u32 n, u32 j) {
+    const u32 s = 2 * (n - 1 - j);
+    const u32 ws = s >> 6, bs = s & 63;
+    const u32 last = P.nw - 1;
+    const u64 t0 = c[ws < last ? ws : last], t1 = c[ws + 1 < last ? ws + 1 : last], t2 = c[ws + 2 < last ? ws + 2 : last];
+    const u64 a0 = ws <= last ? t0 : 0, a1 = ws + 1 <= last ? t1 : 0, a2 = ws + 2 <= last ? t2 : 0;
+    u128x r;
+    r.lo = bs ? ((a0 >> bs) | (a1 << (64 - bs))) : a0;
+    r.hi = bs ? ((a1 >> bs) | (a2 << (64 - bs))) : a1;
+    return and128(r, mask128(2 * P.kb));
+}
+
+#define WI_BATCH 32u   // partitions a wave takes per work-counter atomic
+
+// WI_NI-instances-per-lane body of the expand + de-duplicate phases (NI = 4 when the
+// chunk has <= 256 instances, else 8: all NI instances of a lane are in flight together)
+template <u32 NI>
+__device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane, u32 ninst, u32 tsize, const u64* s_rec, const u32* s_pref,
+                                                  const uint8_t* s_irec, const u32* s_rmult, u64* s_key, u32* s_tab) {
+    u64 klo[NI], khi[NI];
+    u32 hh[NI], mult[NI];
+    u32 rix[NI];
+#pragma unroll
+    for (u32 it = 0; it < NI; it++) {
+        const u32 i = it * 64 + lane;
+        rix[it] = s_irec[i < ninst ? i : 0];
+    }
+#pragma unroll
+    for (u32 it = 0; it < NI; it++) {
+        const u32 i = it * 64 + lane;
+        const u32 r = rix[it];
+        const u64* c = s_rec + r * P.stride;
+        const u64 hdr = c[P.nw];
+        const u32 j = i < ninst ? i - s_pref[r] : 0;
+        const u128x key = make_key(P, hdr_bucket(hdr), record_kmer_lds(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+        klo[it] = key.lo;
+        khi[it] = key.hi;
+        hh[it] = hash_key32(key) & (tsize - 1);
+        mult[it] = s_rmult[r] << WI_CNT_SHIFT;
+        if (i < ninst) {
+            s_key[2 * i] = key.lo;
+            s_key[2 * i + 1] = key.hi;
+        }
+    }
+    wave_sync();
+    // de-duplicate: all of a lane's instances probe in lockstep rounds
+    u32 pending = 0;
+#pragma unroll
+    for (u32 it = 0; it < NI; it++)
+        if (it * 64 + lane < ninst) pending |= 1u << it;
+    while (__any(pending != 0)) {
+        u32 old[NI];
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            old[it] = EMPTY_SLOT;
+            if (pending >> it & 1) old[it] = atomicCAS(&s_tab[hh[it]], EMPTY_SLOT, (it * 64 + lane) | mult[it]);
+        }
+        u64 olo[NI], ohi[NI];
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            const u32 oi = old[it] == EMPTY_SLOT ? 0 : (old[it] & WI_IDX_MASK);
+            olo[it] = s_key[2 * oi];
+            ohi[it] = s_key[2 * oi + 1];
+        }
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            if (pending >> it & 1) {
+                if (old[it] == EMPTY_SLOT) {
+                    pending &= ~(1u << it);
+                } else if (olo[it] == klo[it] && ohi[it] == khi[it]) {
+                    atomicAdd(&s_tab[hh[it]], mult[it]);
+                    pending &= ~(1u << it);
+                } else {
+                    hh[it] = (hh[it] + 1) & (tsize - 1);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+                                               u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
+    __shared__ u64 s_key[2 * WI_MAX_INST];
+    __shared__ u64 s_rec[WI_MAX_REC * 5];
+    __shared__ u32 s_tab[WI_TABLE];
+    __shared__ u32 s_pref[WI_MAX_REC + 1];
+    __shared__ u32 s_list[WI_MAX_INST];
+    __shared__ u32 s_rtab[2 * WI_MAX_REC];
+    __shared__ u32 s_rmult[WI_MAX_REC];
+    __shared__ uint8_t s_irec[WI_MAX_INST];
+
+    const u32 lane = threadIdx.x;
+    unsigned long long acur = ix.slot_cur[blockIdx.x], aend = ix.slot_end[blockIdx.x], garbage = 0;
+    const u32 kbits = 2 * P.kb + 6;
+
+    for (;;) {
+        // ---- take the next batch of partitions (one atomic per WI_BATCH partitions)
+        u32 t0 = 0;
+        if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
+        t0 = __shfl(t0, 0, 64);
+        if (t0 >= n_touched) break;
+        const u32 t_end = min(t0 + WI_BATCH, n_touched);
+        PartDesc d = desc[t0];
+        RecRegs rr = load_rec_regs(P, rec, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane);
+
+        for (u32 t = t0; t < t_end; t++) {
+            // descriptor of the partition after this one: in flight while this one is processed
+            const u32 tn = t + 1;
+            PartDesc dn{};
+            if (tn < t_end) dn = desc[tn];
+            RecRegs rn{0, 0, 0, 0, 0};
+
+            const u32 part = d.part;
+            const u32 r_end = d.r_begin + d.n_rec;
+            u32 n_exist = d.n_exist;
+            u32 inst_left = d.n_inst;  // instances not yet processed: bounds the final size
+            unsigned long long off = d.off;
+            u32 cap = d.cap;
+            u32 bm0 = 0, bm1 = 0;
+
+            for (u32 rc = d.r_begin; rc < r_end;) {
+                // ---- pick the chunk: up to WI_MAX_REC records / WI_MAX_INST instances
+                const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
+                if (rc != d.r_begin) rr = load_rec_regs(P, rec, rc, avail, lane);
+                wave_sync();
+                if (lane < avail) {
+                    u64* dst = s_rec + lane * P.stride;
+                    dst[0] = rr.w0;
+                    dst[1] = rr.w1;
+                    if (P.stride > 2) dst[2] = rr.w2;
+                    if (P.stride > 3) dst[3] = rr.w3;
+                    if (P.stride > 4) dst[4] = rr.w4;
+                }
+                const u64 my_hdr = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
+                const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
+                const u32 x0 = wave_incl_scan(raw_n, lane);
+                // First try every available record: identical records (the same super-k-mer seen in
+                // several reads) collapse into one with a multiplicity, so far more raw instances fit.
+                // If the collapsed chunk is still too big, fall back to the raw-count prefix.
+                u32 nrec = avail, my_n = 0, x = 0, ninst = 0;
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    s_rtab[lane] = EMPTY_SLOT;
+                    s_rtab[lane + 64] = EMPTY_SLOT;
+                    s_rmult[lane] = 1;
+                    wave_sync();
+                    bool dup = false;
+                    if (lane < nrec) {
+                        u64 z = rr.w0 ^ (rr.w1 * 0x9E3779B97F4A7C15ull) ^ (rr.w2 * 0xC2B2AE3D27D4EB4Full) ^ (rr.w3 * 0x165667B19E3779F9ull) ^ (rr.w4 * 0xD6E8FEB86659FD93ull);
+                        z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+                        u32 h = (u32)(z >> 40) & (2 * WI_MAX_REC - 1);
+                        for (;;) {
+                            const u32 o = atomicCAS(&s_rtab[h], EMPTY_SLOT, lane);
+                            if (o == EMPTY_SLOT) break;
+                            const u64* oc = s_rec + o * P.stride;
+                            bool same = oc[0] == rr.w0 && oc[1] == rr.w1;
+                            if (P.stride > 2) same = same && oc[2] == rr.w2;
+                            if (P.stride > 3) same = same && oc[3] == rr.w3;
+                            if (P.stride > 4) same = same && oc[4] == rr.w4;
+                            if (same) {
+                                atomicAdd(&s_rmult[o], 1u);
+                                dup = true;
+                                break;
+                            }
+                            h = (h + 1) & (2 * WI_MAX_REC - 1);
+                        }
+                    }
+                    my_n = (lane < nrec && !dup) ? raw_n : 0;
+                    x = wave_incl_scan(my_n, lane);
+                    ninst = __shfl(x, 63, 64);
+                    if (ninst <= WI_MAX_INST) break;
+                    nrec = (u32)__popcll(__ballot(lane < avail && x0 <= WI_MAX_INST));  // >= 1; a prefix: x0 is monotone
+                    wave_sync();
+                }
+                const u32 raw_inst = __shfl(x0, nrec - 1, 64);
+                u32 tsize = 128;
+                while (tsize < ninst + (ninst >> 1) && tsize < WI_TABLE) tsize <<= 1;
+                s_pref[lane + 1] = x;
+                if (lane == 0) s_pref[0] = 0;
+#pragma unroll
+                for (u32 w = 0; w < WI_TS; w++)
+                    if (w * 64 < tsize) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                {
+                    const u32 start = x - my_n;
+                    for (u32 j = 0; j < my_n; j++) s_irec[start + j] = (uint8_t)lane;
+                }
+                wave_sync();
+                // the next partition's first records: requested now, consumed next iteration
+                if (rc == d.r_begin && tn < t_end) rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
+
+                // ---- 0/1. expand to entry keys and de-duplicate
+                if (ninst <= 256)
+                    expand_and_dedupe<4>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                else
+                    expand_and_dedupe<WI_NI>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                wave_sync();
+
+                // ---- 2. existing entries probe the table
+                for (u32 e = lane; e < n_exist; e += 64) {
+                    const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+                    u32 h = hash_key32(key) & (tsize - 1);
+                    for (;;) {
+                        const u32 v = s_tab[h];
+                        if (v == EMPTY_SLOT) break;
+                        const u32 i = v & WI_IDX_MASK;
+                        if (s_key[2 * i] == key.lo && s_key[2 * i + 1] == key.hi) {
+                            ix.counts[off + e] = (uint8_t)(ix.counts[off + e] + ((v & ~MATCHED_BIT) >> WI_CNT_SHIFT));
+                            s_tab[h] = v | MATCHED_BIT;
+                            break;
+                        }
+                        h = (h + 1) & (tsize - 1);
+                    }
+                }
+                wave_sync();
+
+                // ---- 3. append the unmatched ones: compact them in LDS, then write them out with
+                // full waves (a store instruction costs the same with 3 active lanes as with 64)
+                u32 n_new = 0;
+#pragma unroll
+                for (u32 w = 0; w < WI_TS; w++) {
+                    if (w * 64 < tsize) {
+                        const u32 v = s_tab[w * 64 + lane];
+                        const bool is_new = v != EMPTY_SLOT && !(v & MATCHED_BIT);
+                        const unsigned long long bal = __ballot(is_new);
+                        if (is_new) s_list[n_new + (u32)__popcll(bal & lanes_below(lane))] = v;
+                        n_new += (u32)__popcll(bal);
+                    }
+                }
+                wave_sync();
+                inst_left -= raw_inst;
+                if (n_exist + n_new > cap) {
+                    // move to a fresh slice, sized so that this partition moves at most once per batch
+                    const unsigned long long want = grow_cap(n_exist + n_new + inst_left);
+                    if (acur + want > aend) {  // private chunk exhausted: abandon its tail, take a new one
+                        const unsigned long long grab = want > ARENA_CHUNK ? want : (unsigned long long)ARENA_CHUNK;
+                        garbage += aend - acur;
+                        unsigned long long got = 0;
+                        if (lane == 0) got = atomicAdd(ix.cursor, grab);
+                        acur = __shfl(got, 0, 64);
+                        aend = acur + grab;
+                    }
+                    garbage += cap;
+                    const unsigned long long noff = acur;
+                    acur += want;
+                    cap = (u32)want;
+                    for (u32 e = lane; e < n_exist; e += 64) {
+                        ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
+                        ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (off + e) + 1];
+                        ix.counts[noff + e] = ix.counts[off + e];
+                    }
+                    off = noff;
+                }
+                for (u32 q = lane; q < n_new; q += 64) {
+                    const u32 v = s_list[q];
+                    const u32 i = v & WI_IDX_MASK;
+                    const u64 klo2 = s_key[2 * i], khi2 = s_key[2 * i + 1];
+                    const unsigned long long at = off + n_exist + q;
+                    ix.keys[2 * at] = klo2;
+                    ix.keys[2 * at + 1] = khi2;
+                    ix.counts[at] = (uint8_t)(v >> WI_CNT_SHIFT);
+                    // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here)
+                    const u32 bl = P.shift ? ((u32)shr128(mk128(klo2, khi2), kbits).lo & ((1u << P.shift) - 1)) : 0;
+                    const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;  // 64 bins at most
+                    if (bb < 32) bm0 |= 1u << bb; else bm1 |= 1u << (bb - 32);
+                }
+                n_exist += n_new;
+                rc += nrec;
+                if (rc < r_end) __threadfence();  // the next chunk re-reads what this one appended
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                bm0 |= __shfl_xor(bm0, o, 64);
+                bm1 |= __shfl_xor(bm1, o, 64);
+            }
+            if (lane == 0) ix.dir[part] = DirEnt{off, n_exist, cap};
+            // bucket occupancy bits: exact when a partition holds <= 64 buckets (shift <= 6);
+            // partitions of more buckets are handled by k_bucket_bits below
+            if (P.shift <= 6 && lane < 2) {
+                const u32 mask = lane == 0 ? bm0 : bm1;
+                const u32 nb = 1u << P.shift;  // buckets per partition
+                const u64 first = (u64)part << P.shift;
+                if (mask) {
+                    if (nb >= 32) {
+                        if (lane * 32 < nb) atomicOr(&ix.bucket_bits[(first >> 5) + lane], mask);
+                    } else if (lane == 0) {
+                        atomicOr(&ix.bucket_bits[first >> 5], mask << (first & 31));
+                    }
+                }
+            }
+            d = dn;
+            rr = rn;
+        }
+    }
+    if (lane == 0) {
+        ix.slot_cur[blockIdx.x] = acur;
+        ix.slot_end[blockIdx.x] = aend;
+        if (garbage) atomicAdd(&ix.stats[3], garbage);
+    }
+}
+
+// bucket occupancy for partitions wider than 64 buckets (small part_bits): one pass over all entries
+__global__ void __launch_bounds__(256) k_bucket_bits(BriskParams P, IndexDev ix, u32 n_parts) {
+    const u32 kbits = 2 * P.kb + 6;
+    for (u32 part = blockIdx.x; part < n_parts; part += gridDim.x) {
+        const u32 cnt = ix.dir[part].cnt;
+        const unsigned long long off = ix.dir[part].off;
+        for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+            const u32 bucket = (part << P.shift) | ((u32)shr128(key, kbits).lo & ((1u << P.shift) - 1));
+            const u32 bit = 1u << (bucket & 31);
+            if (!(ix.bucket_bits[bucket >> 5] & bit)) atomicOr(&ix.bucket_bits[bucket >> 5], bit);
+        }
+    }
+}
+
+// stats(): nb_kmers = sum dir_cnt, largest = max dir_cnt, nb_buckets = popcount(bucket_bits)
+__global__ void __launch_bounds__(256) k_stats(const DirEnt* __restrict__ dir, u64 n_parts, const u32* __restrict__ bits, u64 n_words,
+                                               unsigned long long* out /* [0] kmers [1] buckets [2] largest */) {
+    __shared__ unsigned long long s_a[4], s_b[4], s_c[4];
+    unsigned long long a = 0, b = 0, c = 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_parts; i += stride) {
+        const u32 v = dir[i].cnt;
+        a += v;
+        c = v > c ? v : c;
+    }
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) b += __popc(bits[i]);
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+        const unsigned long long c2 = __shfl_down(c, o, 64);
+        c = c2 > c ? c2 : c;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = a;
+        s_b[threadIdx.x >> 6] = b;
+        s_c[threadIdx.x >> 6] = c;
     }
     __syncthreads();
-
-    for (u32 rc = r_begin; rc < r_end;) {
-        // ---- pick the chunk: up to INS_MAX_REC records / INS_MAX_INST instances
-        const u32 avail = min(r_end - rc, (u32)INS_MAX_REC);
-        u32 my_n = 0;
-        if (tid < avail) my_n = hdr_n(rec[(u64)(rc + tid) * P.stride + P.nw]);
-        u32 x = my_n;  // inclusive prefix over the block
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 y = __shfl_up(x, o, 64);
-            if ((int)lane >= o) x += y;
-        }
-        if (lane == 63) s_wave[wid] = x;
-        __syncthreads();
-        u32 woff = 0;
-        for (u32 j = 0; j < wid; j++) woff += s_wave[j];
-        x += woff;
-        if (tid < INS_MAX_REC) s_pref[tid + 1] = x;
-        if (tid == 0) s_pref[0] = 0;
-        __syncthreads();
-        if (tid == 0) {
-            // largest prefix of records whose instances fit (at least one: n <= k-m+1 < INS_MAX_INST)
-            u32 lo = 1, hi = avail;
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if (s_pref[mid] <= INS_MAX_INST) lo = mid; else hi = mid - 1;
-            }
-            s_nrec = lo;
-            s_ninst = s_pref[lo];
-            s_nnew = 0;
-        }
-        for (u32 i = tid; i < INS_TABLE; i += INSERT_BLOCK) {
-            s_tab[i] = EMPTY_SLOT;
-            s_cnt[i] = 0;
-        }
-        __syncthreads();
-        const u32 nrec = s_nrec, ninst = s_ninst;
-        for (u32 i = tid; i < nrec * P.stride; i += INSERT_BLOCK) s_rec[i] = rec[(u64)rc * P.stride + i];
-        __syncthreads();
-
-        // ---- 1. de-duplicate the chunk's instances
-        for (u32 i = tid; i < ninst; i += INSERT_BLOCK) {
-            u32 lo = 0, hi = nrec - 1;  // record of instance i: last r with s_pref[r] <= i
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if (s_pref[mid] <= i) lo = mid; else hi = mid - 1;
-            }
-            const u32 j = i - s_pref[lo];
-            const u128x key = chunk_key(P, s_rec, lo, j);
-            const u32 me = (lo << 6) | j;
-            u32 h = hash_key32(key) & (INS_TABLE - 1);
-            for (;;) {
-                const u32 old = atomicCAS(&s_tab[h], EMPTY_SLOT, me);
-                if (old == EMPTY_SLOT || eq128(chunk_key(P, s_rec, old >> 6, old & 63), key)) {
-                    atomicAdd(&s_cnt[h], 1u);
-                    break;
-                }
-                h = (h + 1) & (INS_TABLE - 1);
-            }
-        }
-        __syncthreads();
-
-        // ---- 2. existing entries probe the table
-        const unsigned long long off = s_off;
-        for (u32 e = tid; e < n_exist; e += INSERT_BLOCK) {
-            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
-            u32 h = hash_key32(key) & (INS_TABLE - 1);
-            for (;;) {
-                const u32 v = s_tab[h];
-                if (v == EMPTY_SLOT) break;
-                if (eq128(chunk_key(P, s_rec, (v & ~MATCHED_BIT) >> 6, v & 63), key)) {
-                    ix.counts[off + e] = (uint8_t)(ix.counts[off + e] + s_cnt[h]);
-                    s_tab[h] = v | MATCHED_BIT;
-                    break;
-                }
-                h = (h + 1) & (INS_TABLE - 1);
-            }
-        }
-        __syncthreads();
-
-        // ---- 3. append the unmatched ones
-        u32 mine = 0;
-        for (u32 i = tid; i < INS_TABLE; i += INSERT_BLOCK) {
-            const u32 v = s_tab[i];
-            mine += (v != EMPTY_SLOT && !(v & MATCHED_BIT));
-        }
-        u32 px = mine;
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 y = __shfl_up(px, o, 64);
-            if ((int)lane >= o) px += y;
-        }
-        if (lane == 63) s_wave[wid] = px;
-        __syncthreads();
-        u32 before = px - mine;
-        for (u32 j = 0; j < wid; j++) before += s_wave[j];
-        const u32 n_new = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        inst_left -= ninst;
-        if (n_exist + n_new > s_cap) {
-            // move to a fresh slice, sized so that this partition moves at most once per batch
-            __syncthreads();
-            if (tid == 0) {
-                const u32 want = grow_cap(n_exist + n_new + inst_left);
-                const unsigned long long noff = atomicAdd(ix.cursor, (unsigned long long)want);
-                atomicAdd(&ix.stats[3], (unsigned long long)s_cap);
-                s_off = noff;
-                s_cap = want;
-            }
-            __syncthreads();
-            const unsigned long long noff = s_off;
-            for (u32 e = tid; e < n_exist; e += INSERT_BLOCK) {
-                ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
-                ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (off + e) + 1];
-                ix.counts[noff + e] = ix.counts[off + e];
-            }
-        }
-        const unsigned long long woffs = s_off;
-        u32 pos = n_exist + before;
-        for (u32 i = tid; i < INS_TABLE; i += INSERT_BLOCK) {
-            const u32 v = s_tab[i];
-            if (v != EMPTY_SLOT && !(v & MATCHED_BIT)) {
-                const u64 hdr = s_rec[(v >> 6) * P.stride + P.nw];
-                const u128x key = chunk_key(P, s_rec, v >> 6, v & 63);
-                ix.keys[2 * (woffs + pos)] = key.lo;
-                ix.keys[2 * (woffs + pos) + 1] = key.hi;
-                ix.counts[woffs + pos] = (uint8_t)s_cnt[i];
-                const u32 bucket = hdr_bucket(hdr);
-                const u32 bit = 1u << (bucket & 31);
-                if (!(ix.bucket_bits[bucket >> 5] & bit)) {
-                    const u32 prev = atomicOr(&ix.bucket_bits[bucket >> 5], bit);
-                    if (!(prev & bit)) atomicAdd(&ix.stats[1], 1ull);
-                }
-                pos++;
-            }
-        }
-        n_exist += n_new;
-        rc += nrec;
-        if (rc < r_end) __threadfence();  // the next chunk re-reads what this one appended
-        __syncthreads();
-    }
-    if (tid == 0) {
-        ix.dir_off[part] = s_off;
-        ix.dir_cnt[part] = n_exist;
-        ix.dir_cap[part] = s_cap;
-        if (n_exist != n_exist0) atomicAdd(&ix.stats[0], (unsigned long long)(n_exist - n_exist0));
-        atomicMax(&ix.stats[2], (unsigned long long)n_exist);
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+        atomicAdd(&out[1], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        unsigned long long m = s_c[0];
+        for (int i = 1; i < 4; i++) m = s_c[i] > m ? s_c[i] : m;
+        atomicMax(&out[2], m);
     }
 }
 
 // ===========================================================================
-// k_query: same table as k_insert, but existing entries add their count to the
-// per-read sums of the instances they match (get_superkmer, Brisk.hpp:102-118).
+// k_query: the same LDS table as k_insert, but every instance keeps its own slot
+// (duplicates sit behind each other in the probe chain) and the partition's
+// entries add their count to the per-read sum of every instance they match
+// (get_superkmer, Brisk.hpp:102-118; summed per read as counter.cpp:296-301 does).
 __global__ void __launch_bounds__(INSERT_BLOCK) k_query(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags,
-                                                        const u32* __restrict__ part_off, const u32* __restrict__ touched,
+                                                        const u32* __restrict__ part_off, const u32* __restrict__ touched, u32 n_touched,
                                                         IndexDev ix, unsigned long long* __restrict__ per_read_sum) {
-    __shared__ u64 s_rec[INS_MAX_REC * 5];
+    __shared__ u64 s_key[2 * INS_MAX_INST];
     __shared__ u32 s_tab[INS_TABLE];
+    __shared__ unsigned short s_irec[INS_MAX_INST];
     __shared__ u32 s_pref[INS_MAX_REC + 1];
     __shared__ u32 s_wave[INSERT_BLOCK / 64];
-    __shared__ u32 s_nrec, s_ninst;
 
     const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const u32 part = touched[blockIdx.x];
-    const u32 r_begin = part_off[part], r_end = part_off[part + 1];
-    const u32 n_exist = ix.dir_cnt[part];
-    const unsigned long long off = ix.dir_off[part];
-    if (n_exist == 0) return;
-
-    for (u32 rc = r_begin; rc < r_end;) {
-        const u32 avail = min(r_end - rc, (u32)INS_MAX_REC);
-        u32 my_n = 0;
-        if (tid < avail) my_n = hdr_n(rec[(u64)(rc + tid) * P.stride + P.nw]);
-        u32 x = my_n;
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 y = __shfl_up(x, o, 64);
-            if ((int)lane >= o) x += y;
-        }
-        if (lane == 63) s_wave[wid] = x;
-        __syncthreads();
-        u32 woff = 0;
-        for (u32 j = 0; j < wid; j++) woff += s_wave[j];
-        x += woff;
-        if (tid < INS_MAX_REC) s_pref[tid + 1] = x;
-        if (tid == 0) s_pref[0] = 0;
-        __syncthreads();
-        if (tid == 0) {
-            u32 lo = 1, hi = avail;
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if (s_pref[mid] <= INS_MAX_INST) lo = mid; else hi = mid - 1;
+    for (u32 t = blockIdx.x; t < n_touched; t += gridDim.x) {
+        const u32 part = touched[t];
+        const u32 r_begin = part_off[part], r_end = part_off[part + 1];
+        const u32 n_exist = ix.dir[part].cnt;
+        const unsigned long long off = ix.dir[part].off;
+        if (n_exist == 0) continue;
+        for (u32 rc = r_begin; rc < r_end;) {
+            __syncthreads();
+            const u32 avail = min(r_end - rc, (u32)INS_MAX_REC);
+            u64 my_hdr = 0;
+            if (tid < avail) my_hdr = rec[(u64)(rc + tid) * P.stride + P.nw];
+            u32 x = hdr_n(my_hdr);
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 y = __shfl_up(x, o, 64);
+                if ((int)lane >= o) x += y;
             }
-            s_nrec = lo;
-            s_ninst = s_pref[lo];
-        }
-        for (u32 i = tid; i < INS_TABLE; i += INSERT_BLOCK) s_tab[i] = EMPTY_SLOT;
-        __syncthreads();
-        const u32 nrec = s_nrec, ninst = s_ninst;
-        for (u32 i = tid; i < nrec * P.stride; i += INSERT_BLOCK) s_rec[i] = rec[(u64)rc * P.stride + i];
-        __syncthreads();
-        // every instance gets its own slot (duplicates chain behind each other)
-        for (u32 i = tid; i < ninst; i += INSERT_BLOCK) {
-            u32 lo = 0, hi = nrec - 1;
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if (s_pref[mid] <= i) lo = mid; else hi = mid - 1;
+            if (lane == 63) s_wave[wid] = x;
+            __syncthreads();
+            u32 woff = 0;
+            for (u32 j = 0; j < wid; j++) woff += s_wave[j];
+            x += woff;
+            if (tid < INS_MAX_REC) s_pref[tid + 1] = x;
+            if (tid == 0) s_pref[0] = 0;
+            __syncthreads();
+            const unsigned long long fb = __ballot(tid < avail && x <= INS_MAX_INST);
+            if (lane == 0) s_wave[wid] = (u32)__popcll(fb);
+            __syncthreads();
+            const u32 nrec = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            const u32 ninst = s_pref[nrec];
+            for (u32 i = tid; i < INS_TABLE; i += INSERT_BLOCK) s_tab[i] = EMPTY_SLOT;
+            for (u32 r = wid; r < nrec; r += INSERT_BLOCK / 64) {
+                const u64* c = rec + (u64)(rc + r) * P.stride;
+                const u64 hdr = c[P.nw];
+                const u32 n = hdr_n(hdr);
+                if (lane < n) {
+                    const u128x key = make_key(P, hdr_bucket(hdr), record_kmer(P, c, n, lane), hdr_idx0(hdr) + lane);
+                    const u32 i = s_pref[r] + lane;
+                    s_key[2 * i] = key.lo;
+                    s_key[2 * i + 1] = key.hi;
+                    s_irec[i] = (unsigned short)r;
+                }
             }
-            const u32 j = i - s_pref[lo];
-            const u128x key = chunk_key(P, s_rec, lo, j);
-            u32 h = hash_key32(key) & (INS_TABLE - 1);
-            while (atomicCAS(&s_tab[h], EMPTY_SLOT, (lo << 6) | j) != EMPTY_SLOT) h = (h + 1) & (INS_TABLE - 1);
-        }
-        __syncthreads();
-        for (u32 e = tid; e < n_exist; e += INSERT_BLOCK) {
-            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
-            const u32 cnt = ix.counts[off + e];
-            u32 h = hash_key32(key) & (INS_TABLE - 1);
-            for (;;) {
-                const u32 v = s_tab[h];
-                if (v == EMPTY_SLOT) break;
-                if (eq128(chunk_key(P, s_rec, v >> 6, v & 63), key)) atomicAdd(&per_read_sum[tags[rc + (v >> 6)]], (unsigned long long)cnt);
-                h = (h + 1) & (INS_TABLE - 1);
+            __syncthreads();
+            for (u32 i = tid; i < ninst; i += INSERT_BLOCK) {
+                u32 h = hash_key32(mk128(s_key[2 * i], s_key[2 * i + 1])) & (INS_TABLE - 1);
+                while (atomicCAS(&s_tab[h], EMPTY_SLOT, i) != EMPTY_SLOT) h = (h + 1) & (INS_TABLE - 1);
             }
+            __syncthreads();
+            for (u32 e = tid; e < n_exist; e += INSERT_BLOCK) {
+                const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+                const u32 cnt = ix.counts[off + e];
+                u32 h = hash_key32(key) & (INS_TABLE - 1);
+                for (;;) {
+                    const u32 v = s_tab[h];
+                    if (v == EMPTY_SLOT) break;
+                    if (s_key[2 * v] == key.lo && s_key[2 * v + 1] == key.hi)
+                        atomicAdd(&per_read_sum[tags[rc + s_irec[v]]], (unsigned long long)cnt);
+                    h = (h + 1) & (INS_TABLE - 1);
+                }
+            }
+            rc += nrec;
         }
-        rc += nrec;
-        __syncthreads();
     }
 }
 
 // ===========================================================================
 // k_enumerate: entries of partitions [p_begin, p_end) in order; out_base[p - p_begin]
 // is the exclusive prefix of dir_cnt over that range (Brisk::next yields unhashed k-mers).
-__global__ void __launch_bounds__(256) k_dir_prefix_block(const u32* __restrict__ dir_cnt, u64 n, u32* __restrict__ block_sums) {
-    __shared__ u32 s[4];
-    const u64 base = (u64)blockIdx.x * 256 * SCAN_ITEMS;
-    u32 acc = 0;
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const u64 j = base + (u64)i * 256 + threadIdx.x;
-        if (j < n) acc += dir_cnt[j];
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+__global__ void __launch_bounds__(256) k_dir_counts(const DirEnt* __restrict__ dir, u64 n, u32* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dir[i].cnt;
 }
 
 __global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u32 p_begin, u32 n_parts, const u64* __restrict__ out_base,
@@ -716,8 +955,8 @@ __global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u3
     const u32 pi = blockIdx.x;
     if (pi >= n_parts) return;
     const u32 part = p_begin + pi;
-    const u32 cnt = ix.dir_cnt[part];
-    const unsigned long long off = ix.dir_off[part];
+    const u32 cnt = ix.dir[part].cnt;
+    const unsigned long long off = ix.dir[part].off;
     const u64 ob = out_base[pi];
     for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
         const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
@@ -755,8 +994,8 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
         const u128x comp = or128(andn128(shr128(km, 2 * P.b), lowm), and128(km, lowm));
         const u128x key = make_key(P, bucket, and128(comp, mask128(2 * P.kb)), cut);
         const u32 part = bucket >> P.shift;
-        const u32 cnt = ix.dir_cnt[part];
-        const unsigned long long off = ix.dir_off[part];
+        const u32 cnt = ix.dir[part].cnt;
+        const unsigned long long off = ix.dir[part].off;
         for (u32 e = lane; e < cnt && !found; e += 64) {
             if (ix.keys[2 * (off + e)] == key.lo && ix.keys[2 * (off + e) + 1] == key.hi) {
                 found = true;

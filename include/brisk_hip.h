@@ -71,7 +71,7 @@ typedef struct brisk_hip_options {
     uint32_t struct_size;       /* sizeof(brisk_hip_options), for ABI growth */
     int32_t device;             /* HIP device ordinal */
     void *stream;               /* hipStream_t to run on, NULL: the library creates one */
-    uint32_t part_bits;         /* log2(#partitions); 0: default min(2b, 22) */
+    uint32_t part_bits;         /* log2(#partitions); 0: default min(2b, 24) */
     uint32_t owner_rank;        /* this process' rank among n_owners bucket-range owners */
     uint32_t n_owners;          /* 0 or 1: this index owns every bucket */
     uint64_t arena_entries;     /* initial entry capacity of the k-mer arena; 0: grow on demand */
