@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,11 @@ struct brisk_hip_index {
     u64 max_batch_reads = 0;
 
     double* d_coef = nullptr;
+    double* d_tabs = nullptr;   // coef[128] + decycling chunk tables, staged to LDS by k_scan2
+    ScanCfg scfg{};
+    u32 scan_waves = 0;         // waves per k_scan2 block
+    size_t scan_lds = 0;
+    bool scan_v1 = false;       // BRISK_SCAN_V1=1: the plain restatement kernel
     // the index
     u64 arena_cap = 0;
     u64 arena_used_host = 0;
@@ -221,8 +227,14 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
     ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags};
     {
         ProfScope ps(h, S_SCAN);
-        hipLaunchKernelGGL(k_scan, dim3(nblocks(n_reads, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_reads,
-                           h->d_coef, out, query_mode ? 1 : 0);
+        if (h->scan_v1) {
+            hipLaunchKernelGGL(k_scan, dim3(nblocks(n_reads, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_reads,
+                               h->d_coef, out, query_mode ? 1 : 0);
+        } else {
+            const u32 bt = h->scan_waves * 64;
+            hipLaunchKernelGGL(k_scan2, dim3(nblocks(n_reads, bt)), dim3(bt), h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads,
+                               h->d_tabs, out, query_mode ? 1 : 0);
+        }
         int rc;
         if ((rc = launch_check(h, "k_scan"))) return rc;
     }
@@ -362,6 +374,7 @@ void free_all(brisk_hip_index* h) {
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);
+    fr(h->d_tabs);
     fr(h->ix.keys);
     fr(h->ix.counts);
     fr(h->ix.dir);
@@ -443,6 +456,43 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMalloc((void**)&h->d_coef, 128 * sizeof(double)));
         HIPCHK(h, hipMemsetAsync(h->d_coef, 0, 128 * sizeof(double), h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_coef, coef_table, 4 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        {
+            // decycling chunk tables (host, from the caller's libm table): 4 nts per chunk.
+            // R(x)      = sum_{i=0}^{m-2} coef[4(m-1-i) + nt_i(x)]          (Decycling.cpp:17-24)
+            // R(rot(x)) = sum_{i=1}^{m-1} coef[4(m-i)   + nt_i(x)]          (rot: Decycling.cpp:41)
+            ScanCfg& c = h->scfg;
+            c.nlow = std::min<u32>(32, k);
+            c.nlow1 = std::min<u32>(32, k - 1);
+            c.R = c.nlow - m + 1;
+            c.R_init = c.nlow1 - m + 1;
+            c.pitch = c.R | 1;
+            c.nch = (m - 1 + 3) / 4;
+            c.qcap = 128;
+            const u32 n_tab = 128 + 2 * c.nch * 256;
+            std::vector<double> tabs(n_tab, 0.0);
+            for (u32 i = 0; i < 4u * m; i++) tabs[i] = coef_table[i];
+            for (u32 ch = 0; ch < c.nch; ch++)
+                for (u32 v = 0; v < 256; v++) {
+                    double a = 0.0, bsum = 0.0;
+                    for (u32 i = 4 * ch; i < 4 * ch + 4 && i + 1 < m; i++) a += coef_table[4 * (m - 1 - i) + ((v >> (2 * (i - 4 * ch))) & 3)];
+                    for (u32 i = 1 + 4 * ch; i < 5 + 4 * ch && i < m; i++) bsum += coef_table[4 * (m - i) + ((v >> (2 * (i - 1 - 4 * ch))) & 3)];
+                    tabs[128 + ch * 256 + v] = a;
+                    tabs[128 + (c.nch + ch) * 256 + v] = bsum;
+                }
+            HIPCHK(h, hipMalloc((void**)&h->d_tabs, n_tab * sizeof(double)));
+            HIPCHK(h, hipMemcpyAsync(h->d_tabs, tabs.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const size_t per_wave = (size_t)(64 * c.pitch + 2 * c.qcap) * 8, fixed = (size_t)n_tab * 8;
+            const size_t lds_max = 160 * 1024;
+            u32 wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);
+            if (wv >= 8 && wv < 16) wv = 8;  // prefer a block size that divides the CU's wave slots
+            if (wv < 1) return fail(h, BRISK_HIP_EUNSUPPORTED, "scan state does not fit LDS");
+            h->scan_waves = wv;
+            h->scan_lds = fixed + wv * per_wave;
+            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
+            const char* v1 = getenv("BRISK_SCAN_V1");
+            h->scan_v1 = v1 && v1[0] == '1';
+        }
         const u64 np = h->n_parts;
         HIPCHK(h, hipMalloc((void**)&h->ix.dir, np * sizeof(DirEnt)));
         HIPCHK(h, hipMalloc((void**)&h->ix.cursor, 8));

@@ -280,6 +280,314 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(BriskParams P, const u32* _
     }
 }
 
+__device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1ull << lane) - 1; }
+
+// ===========================================================================
+// k_scan2: the production scan.  Same results as k_scan (kept above as the plain
+// restatement used for A/B), restructured for the wave:
+//   * one lane per read steps the candidate m-mer; its order key is a table-driven
+//     decycling class (4-nt chunk sums in LDS, exact fold only inside a 1e-9 guard
+//     band around +-eps) plus the integer mixer;
+//   * the last R keys of every lane sit in an LDS ring, so a re-scan (get_minimizer,
+//     Kmers.cpp:367-408) reuses them for the windows that lie inside the low 64 bits
+//     and computes only the "fake" zero-padded windows (F2);
+//   * a re-scan is done by the whole wave, one window per lane, using the closed form
+//     of the tie rules (first and last position of the minimum key);
+//   * closed super-k-mers are queued in LDS and turned into records by full waves.
+struct ScanCfg {
+    u32 R;        // real windows of a k-mer: min(32,k) - m + 1  == ring depth
+    u32 R_init;   // real windows of the (k-1)-mer
+    u32 pitch;    // ring row pitch in u64 (odd)
+    u32 nlow;     // min(32, k)
+    u32 nlow1;    // min(32, k-1)
+    u32 nch;      // 4-nt chunks of a decycling sum: ceil((m-1)/4)
+    u32 qcap;     // emit queue entries per wave
+};
+
+// class from chunk tables: tabs[c][v] (R) and tabs[nch+c][v] (R of the rotation)
+__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const double* tabs, const double* coef) {
+    double r = 0.0, rr = 0.0;
+    for (u32 c = 0; c < nch; c++) {
+        r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+        rr += tabs[(nch + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
+    }
+    const double eps = 0.000001, g = 1e-9;
+    // any summation order is within ~1e-13 of the reference's fold; inside the guard band redo it exactly
+    if (fabs(fabs(r) - eps) < g || fabs(fabs(rr) - eps) < g) return decy_class(x, m, coef);
+    if (r > eps) return rr < eps ? 0u : 2u;
+    if (r < -eps) return rr > -eps ? 1u : 2u;
+    return 2u;
+}
+__device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, const double* tabs, const double* coef) {
+    return ((u64)decy_class_fast(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 y = __shfl_xor(v, o, 64);
+        v = y < v ? y : v;
+    }
+    return v;
+}
+
+// closed form of get_minimizer's fold (Kmers.cpp:377-405) given the first and last window
+// holding the minimum key, their `reversed` flags and K-m
+__device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first, bool rev_last, u32 Km, bool canon_if_needed_known, bool canon,
+                                             u32* pos, bool* rev, bool* need_canon) {
+    *need_canon = false;
+    *pos = first;
+    *rev = rev_first;
+    if (last != first) {
+        const u32 dT = Km - last;
+        if (dT < first) {
+            *pos = dT;
+            *rev = rev_last;
+        } else if (dT == first) {
+            if (!canon_if_needed_known) *need_canon = true;
+            else if (!canon) *rev = false;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
+                                                u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, int query_mode) {
+    extern __shared__ double smem_d[];
+    double* s_coef = smem_d;             // 128
+    double* s_tabs = smem_d + 128;       // 2*nch*256
+    const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const u32 n_tab = 128 + 2 * cfg.nch * 256;
+    for (u32 i = tid; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
+    u64* wbase = (u64*)(smem_d + n_tab) + (size_t)wid * (64 * cfg.pitch + 2 * cfg.qcap);
+    u64* ring = wbase + lane * cfg.pitch;          // this lane's row
+    u64* q_start = wbase + 64 * cfg.pitch;         // [qcap] stream index of the super-k-mer's first nt
+    u32* q_misc = (u32*)(q_start + cfg.qcap);      // [qcap] n | idx_end<<8 | rev<<16
+    u32* q_tag = q_misc + cfg.qcap;                // [qcap] read index
+    __syncthreads();
+
+    const u32 k = P.k, m = P.m, w = P.w, nch = cfg.nch;
+    const u64 M = P.m_mask;
+    const u64 r = (u64)blockIdx.x * blockDim.x + tid;
+    u64 q0 = 0, len = 0;
+    if (r < n_reads) {
+        q0 = starts[r];
+        len = starts[r + 1] - q0;
+    }
+    const bool live = len >= k;  // counter.cpp:233-235
+    u32 nk = live ? (u32)(len - k + 1) : 0;
+    u32 max_nk = nk;
+    for (int o = 32; o > 0; o >>= 1) {
+        const u32 y = __shfl_xor(max_nk, o, 64);
+        max_nk = y > max_nk ? y : max_nk;
+    }
+    if (max_nk == 0) return;
+    const u64 KEY0 = order_key_fast(0, m, M, nch, s_tabs, s_coef);
+
+    // ---- prologue: candidate state just before step -R_init, then R_init steps into the ring
+    const u32 Ri = cfg.R_init, R = cfg.R;
+    const u32 j0 = k - cfg.nlow1 - 1;  // first nt of the m-mer of step -R_init
+    u64 cf = 0, cr = 0, low64 = 0, revhist = 0;
+    if (live) {
+        if (m > 1) {
+            cf = load_nts(packed, q0 + j0, m - 1);
+            cr = rc64(cf, m - 1) << 2;
+        }
+    }
+    u32 slot = 0;  // ring slot of the next step
+    for (u32 s = 0; s < Ri; s++) {
+        u32 c = 0;
+        if (live) c = nt_at(packed, q0 + j0 + m - 1 + s);
+        cf = ((cf << 2) + c) & M;
+        cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
+        const bool revf = cr < cf;
+        ring[slot] = order_key_fast(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
+        revhist = (revhist << 1) | (revf ? 1ull : 0ull);
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    if (live) low64 = load_nts(packed, q0 + (k - 1) - cfg.nlow1, cfg.nlow1);
+
+    // ---- minimizer of the (k-1)-mer (Kmers.cpp:533): every lane at once, windows in lockstep
+    u64 mini_hash;
+    u32 mini_pos;
+    bool reversed;
+    {
+        const u32 Km = k - 1 - m;
+        u64 best = ~0ull;
+        u32 first = 0, last = 0;
+        bool rf = false, rl = false;
+        for (u32 i = 0; i <= Km; i++) {
+            u64 key;
+            bool rv;
+            if (i + m <= cfg.nlow1) {  // inside the low 64 bits: the key of step -1-i
+                key = ring[(slot + R - 1 - i) % R];
+                rv = (revhist >> i) & 1;
+            } else if (i < cfg.nlow1) {  // zero-padded window (F2)
+                const u64 fwd = (low64 >> (2 * i)) & M;
+                const u64 rcv = rc64(fwd, m);
+                rv = rcv < fwd;
+                key = order_key_fast(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+            } else {  // beyond the low 64 bits: the all-A m-mer
+                key = KEY0;
+                rv = false;
+            }
+            if (key < best) {
+                best = key;
+                first = last = i;
+                rf = rl = rv;
+            } else if (key == best) {
+                last = i;
+                rl = rv;
+            }
+        }
+        u32 pos;
+        bool rev, need_canon;
+        resolve_ties(first, last, rf, rl, Km, false, false, &pos, &rev, &need_canon);
+        if (need_canon && live) {
+            const u64 hi = k - 1 > 32 ? load_nts(packed, q0, k - 1 - 32) : 0;
+            if (!canonized_as_executed(mk128(low64, hi), k - 1)) rev = false;
+        }
+        mini_hash = best;
+        mini_pos = pos;
+        reversed = rev;
+    }
+
+    // ---- the stream of k-mers
+    u32 qcount = 0;  // wave-uniform
+    u32 n = 0, p0 = 0, first_idx = 0, last_idx = 0, n_emitted = 0;
+    bool dead = false;
+    u64 buf = 0;
+    const u32 Km = k - m;
+    for (u32 p = 0; p < max_nk; p++) {
+        const bool act = p < nk && !dead;
+        if ((p & 31) == 0 && p < nk) {
+            const u32 left = (u32)(len - (k - 1 + p));
+            const u32 cnt = left < 32 ? left : 32;
+            buf = load_nts(packed, q0 + k - 1 + p, cnt) << (64 - 2 * cnt);
+        }
+        const u32 c = (u32)(buf >> 62);
+        buf <<= 2;
+        cf = ((cf << 2) + c) & M;
+        cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
+        low64 = (low64 << 2) | c;
+        const bool revf = cr < cf;
+        const u64 h = order_key_fast(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
+        revhist = (revhist << 1) | (revf ? 1ull : 0ull);
+        ring[slot] = h;
+        const u32 cur_slot = slot;
+        slot = slot + 1 == R ? 0 : slot + 1;
+        mini_pos++;
+        const bool expired = act && mini_pos > w;                  // Kmers.cpp:551
+        const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
+        const bool closed = expired || newmin;
+        // the vector closed by this step (Kmers.cpp:585-588); a close at p == 0 is ignored (:590-592)
+        bool push = closed && p > 0;
+        if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) {  // counter.cpp:304-306: returned minimizer == 0
+            push = false;
+            dead = true;
+        }
+        {
+            const unsigned long long bal = __ballot(push);
+            if (push) {
+                const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
+                q_start[at] = q0 + p0;
+                q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16);
+                q_tag[at] = (u32)r;
+                n_emitted++;
+            }
+            qcount += (u32)__popcll(bal);
+        }
+        // re-scans, one lane's k-mer at a time, one window per lane
+        unsigned long long need = __ballot(expired && !dead);
+        while (need) {
+            const int L = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const u64 lowL = __shfl(low64, L, 64);
+            const u64 rhL = __shfl(revhist, L, 64);
+            u64 key = ~0ull;
+            bool rv = false;
+            if (lane <= Km) {
+                if (lane + m <= cfg.nlow) {
+                    key = wbase[(u32)L * cfg.pitch + (cur_slot + R - lane) % R];
+                    rv = (rhL >> lane) & 1;
+                } else if (lane >= cfg.nlow) {
+                    key = KEY0;
+                }
+            }
+            {
+                // zero-padded windows: computed by their lanes (all lanes run the code, few keep the result)
+                const bool fake = lane <= Km && lane + m > cfg.nlow && lane < cfg.nlow;
+                if (__any(fake)) {
+                    const u64 fwd = (lowL >> (2 * (lane & 31))) & M;
+                    const u64 rcv = rc64(fwd, m);
+                    const bool rv2 = rcv < fwd;
+                    const u64 k2 = order_key_fast(rv2 ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+                    if (fake) {
+                        key = k2;
+                        rv = rv2;
+                    }
+                }
+            }
+            const u64 hmin = wave_min_u64(key);
+            const unsigned long long tie = __ballot(key == hmin);
+            const unsigned long long rvb = __ballot(rv);
+            const u32 first = (u32)__ffsll((long long)tie) - 1, last = 63u - (u32)__clzll((long long)tie);
+            u32 pos;
+            bool rev, need_canon;
+            resolve_ties(first, last, (rvb >> first) & 1, (rvb >> last) & 1, Km, false, false, &pos, &rev, &need_canon);
+            if (need_canon) {  // wave-uniform
+                const u64 qL = __shfl(q0, L, 64) + p;
+                const u64 hi = k > 32 ? load_nts(packed, qL, k - 32) : 0;
+                const u64 lo = k >= 32 ? lowL : (lowL & ((1ull << (2 * k)) - 1));
+                if (!canonized_as_executed(mk128(lo, hi), k)) rev = false;
+            }
+            if ((int)lane == L) {
+                mini_hash = hmin;
+                mini_pos = pos;
+                reversed = rev;
+            }
+        }
+        if (newmin) {  // Kmers.cpp:572-576
+            mini_hash = h;
+            mini_pos = 0;
+            reversed = revf;
+        }
+        if (act) {
+            const u32 idx = reversed ? w - mini_pos : mini_pos;  // Kmers.cpp:578-584
+            if (closed && p > 0) n = 0;
+            if (n == 0) {
+                p0 = p;
+                first_idx = idx;
+            }
+            last_idx = idx;
+            n++;
+        }
+        // turn queued super-k-mers into records with full waves
+        if (qcount + 64 > cfg.qcap) {
+            for (u32 e = lane; e < qcount; e += 64) {
+                const u32 mi = q_misc[e];
+                emit_record(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e]);
+            }
+            qcount = 0;
+        }
+    }
+    // the last vector of every read (Kmers.cpp:596-601)
+    {
+        bool push = live && !dead && n > 0;
+        if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) push = false;
+        const unsigned long long bal = __ballot(push);
+        if (push) {
+            const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
+            q_start[at] = q0 + p0;
+            q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16);
+            q_tag[at] = (u32)r;
+        }
+        qcount += (u32)__popcll(bal);
+    }
+    for (u32 e = lane; e < qcount; e += 64) {
+        const u32 mi = q_misc[e];
+        emit_record(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e]);
+    }
+}
+
 // ===========================================================================
 // exclusive prefix sum over the low 32 bits of the 64-bit histogram
 #define SCAN_ITEMS 16
@@ -508,7 +816,6 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 x, u32 lane) {
     }
     return x;
 }
-__device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1ull << lane) - 1; }
 
 #define WI_NI (WI_MAX_INST / 64)   // instances per lane
 #define WI_TS (WI_TABLE / 64)      // table words per lane
