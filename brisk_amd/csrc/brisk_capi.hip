@@ -797,6 +797,23 @@ BRISK_API int brisk_hip_synth_reads(brisk_hip_index* h, uint64_t genome_len, uin
     return launch_check(h, "k_synth");
 }
 
+BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mmers, uint64_t n, int exact, uint64_t* keys) {
+    if (!h || (n && (!mmers || !keys))) return BRISK_HIP_EINVAL;
+    if (!n) return BRISK_HIP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->lookup_buf, n * 16))) return rc;
+    u64* d_x = (u64*)h->lookup_buf.p;
+    u64* d_k = d_x + n;
+    HIPCHK(h, hipMemcpyAsync(d_x, mmers, n * 8, hipMemcpyHostToDevice, h->stream));
+    const size_t lds = (size_t)(128 + 2 * h->scfg.nch * 256) * 8;
+    hipLaunchKernelGGL(k_debug_keys, dim3(nblocks(n, 256)), dim3(256), lds, h->stream, h->P, h->scfg.nch, h->d_tabs, d_x, n, exact, d_k);
+    if ((rc = launch_check(h, "k_debug_keys"))) return rc;
+    HIPCHK(h, hipMemcpyAsync(keys, d_k, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BRISK_HIP_OK;
+}
+
 // ---- measurement ---------------------------------------------------------------
 BRISK_API int brisk_hip_profile_enable(brisk_hip_index* h, int on) {
     if (!h) return BRISK_HIP_EINVAL;

@@ -322,6 +322,17 @@ __device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, cons
     return ((u64)decy_class_fast(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
 }
 
+__global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, const double* __restrict__ g_tabs, const u64* __restrict__ x, u64 n,
+                                                    int exact, u64* __restrict__ out) {
+    extern __shared__ double smem_d[];
+    const u32 n_tab = 128 + 2 * nch * 256;
+    for (u32 i = threadIdx.x; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, smem_d + 128, smem_d);
+}
+
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
     for (int o = 32; o > 0; o >>= 1) {
         const u64 y = __shfl_xor(v, o, 64);

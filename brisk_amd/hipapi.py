@@ -74,7 +74,7 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_profile_enable",
+    "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
 
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
     L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
     L.brisk_hip_pack_ascii.argtypes = [vp, vp, u64, vp]
     L.brisk_hip_synth_reads.argtypes = [vp, u64, u64, u64, u32, u64, u64, vp, vp]
+    L.brisk_hip_debug_order_keys.argtypes = [vp, _u64p, u64, i32, _u64p]
     L.brisk_hip_profile_enable.argtypes = [vp, i32]
     L.brisk_hip_profile_read.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]
     L.brisk_hip_profile_reset.argtypes = [vp]
@@ -261,6 +262,12 @@ class BriskHip:
     def synth_reads(self, genome_len: int, first_read: int, n_reads: int, read_len: int, d_packed: int, d_starts: int,
                     seed_g: int = 1, seed_r: int = 2):
         self._chk(self.L.brisk_hip_synth_reads(self.h, genome_len, first_read, n_reads, read_len, seed_g, seed_r, d_packed, d_starts))
+
+    def debug_order_keys(self, mmers, exact: bool = False) -> np.ndarray:
+        x = np.ascontiguousarray(mmers, np.uint64)
+        out = np.zeros(max(len(x), 1), np.uint64)
+        self._chk(self.L.brisk_hip_debug_order_keys(self.h, x, len(x), 1 if exact else 0, out))
+        return out[: len(x)]
 
     # ---- measurement
     def profile_enable(self, on: bool = True):

@@ -42,6 +42,8 @@
  *   brisk_hip_pack_ascii        nuc2int (brisk/Kmers.cpp:442-444) applied in bulk
  *   brisk_hip_synth_reads       no reference counterpart (benchmark input,
  *                               SURVEY.md 8(d))
+ *   brisk_hip_debug_order_keys  bfc_hash_64 + DecyclingSet::memDouble in bulk
+ *                               (brisk/hashing.cpp:8-19, brisk/Decycling.cpp:38-52); test hook
  */
 #ifndef BRISK_HIP_H
 #define BRISK_HIP_H
@@ -158,6 +160,12 @@ int brisk_hip_pack_ascii(brisk_hip_index *h, const char *d_bases, uint64_t n_bas
 int brisk_hip_synth_reads(brisk_hip_index *h, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                           uint32_t read_len, uint64_t seed_g, uint64_t seed_r,
                           uint32_t *d_packed, uint64_t *d_starts);
+
+/* ---- test hooks -------------------------------------------------------------- */
+/* order keys (bfc_hash_64, brisk/hashing.cpp:8-19) of n m-mers, computed by the device
+ * code path the scan uses (table-driven class with guard band when exact == 0, the
+ * plain FP64 fold when exact != 0).  HOST arrays. */
+int brisk_hip_debug_order_keys(brisk_hip_index *h, const uint64_t *mmers, uint64_t n, int exact, uint64_t *keys);
 
 /* ---- measurement ----------------------------------------------------------- */
 /* With profiling on, every kernel launch is bracketed by HIP events on the

@@ -267,3 +267,64 @@ def test_empty_inputs(B):
         assert ix.stats()["nb_kmers"] == 0
         assert len(ix.enumerate()[0]) == 0
         assert list(ix.get_reads(["ACGT", ""])) == [0, 0]
+
+
+def test_order_keys_fast_and_exact_paths(B, O):
+    """a2/a3 on device: the table-driven class (with its guard band) and the plain FP64
+    fold both equal the reference's keys, on random and on low-complexity m-mers (where
+    R(x) is mathematically 0 and only rounding noise decides nothing)."""
+    rng = random.Random(77)
+    for k, m, b in ((63, 21, 14), (31, 11, 4), (63, 31, 12), (21, 7, 3), (31, 15, 14)):
+        M = (1 << (2 * m)) - 1
+        xs = [rng.getrandbits(2 * m) for _ in range(200000)]
+        for unit in ("A", "C", "G", "T", "AC", "AG", "AT", "CG", "CT", "GT", "ACG", "ACT", "AAC", "ACGT", "AACC", "ACCGT"):
+            for rot in range(len(unit)):
+                xs.append(oracle.str2kmer(((unit[rot:] + unit[:rot]) * m)[:m])[0])
+        xs += [0, M, 1, M - 1, M >> 2]
+        # fake (zero-padded) windows of the k>32 re-scan: short prefixes
+        xs += [rng.getrandbits(2 * rng.randint(1, m - 1)) for _ in range(20000)]
+        want = O.key_many(xs[:20000] + xs[200000:], m)
+        g = load_golden("units.json.gz").get(str(m))
+        with B.BriskHip(k, m, b, part_bits=2) as ix:
+            fast = ix.debug_order_keys(xs)
+            exact = ix.debug_order_keys(xs, exact=True)
+            assert np.array_equal(fast, exact)
+            assert np.array_equal(np.concatenate([fast[:20000], fast[200000:]]), want)
+            if g:
+                gx = [int(x, 16) for x in g["x"]]
+                assert [f"{int(v):x}" for v in ix.debug_order_keys(gx)] == g["key"]
+
+
+def test_periodic_reads_force_minimizer_ties(B, O):
+    """Repeats make the same m-mer the minimum at several windows: every branch of
+    get_minimizer's tie rules (Kmers.cpp:389-404), incl. canonized(), is taken."""
+    rng = random.Random(123)
+    reads = []
+    for period in range(1, 40):
+        for _ in range(6):
+            unit = "".join(rng.choice("ACGT") for _ in range(period))
+            L = rng.choice((150, 151, 200, 97))
+            s = (unit * (L // period + 1))[:L]
+            reads.append(s)
+            # a repeat embedded in random flanks, and its reverse complement
+            fl = "".join(rng.choice("ACGT") for _ in range(40))
+            t = fl + s[:80] + fl[::-1]
+            reads.append(t)
+            reads.append(t[::-1].translate(str.maketrans("ACGT", "TGCA")))
+    for k, m, b in ((31, 11, 4), (63, 21, 14), (33, 11, 7), (63, 31, 12), (41, 21, 5)):
+        assert gpu_count(B, reads, k, m, b) == O.count(reads, k, m, b)
+        with B.BriskHip(k, m, b) as ix:
+            ix.insert_reads(reads)
+            flat, offs = oracle.pack_reads(reads)
+            h = O.index_new(k, m, b)
+            O.index_insert_reads(h, flat, offs)
+            assert np.array_equal(ix.get_reads(reads), O.index_query_reads(h, flat, offs))
+            O.index_free(h)
+
+
+def test_long_sequences_and_ragged_lengths(B, O):
+    rng = random.Random(9)
+    reads = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (63, 64, 65, 95, 96, 97, 127, 128, 129, 1000, 5000, 20011)]
+    reads += ["A" * 3000, ("ACGTTGCA" * 500)]
+    for k, m, b in ((63, 21, 14), (31, 11, 11)):
+        assert gpu_count(B, reads, k, m, b) == O.count(reads, k, m, b)
