@@ -232,8 +232,13 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
                                h->d_coef, out, query_mode ? 1 : 0);
         } else {
             const u32 bt = h->scan_waves * 64;
-            hipLaunchKernelGGL(k_scan2, dim3(nblocks(n_reads, bt)), dim3(bt), h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads,
-                               h->d_tabs, out, query_mode ? 1 : 0);
+            const dim3 grid(nblocks(n_reads, bt)), block(bt);
+            const int qm = query_mode ? 1 : 0;
+            switch (h->scfg.nch) {  // unrolled table lookups for the common minimizer sizes
+                case 5: hipLaunchKernelGGL(k_scan2<5>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads, h->d_tabs, out, qm); break;
+                case 3: hipLaunchKernelGGL(k_scan2<3>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads, h->d_tabs, out, qm); break;
+                default: hipLaunchKernelGGL(k_scan2<0>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads, h->d_tabs, out, qm);
+            }
         }
         int rc;
         if ((rc = launch_check(h, "k_scan"))) return rc;
@@ -489,7 +494,9 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             if (wv < 1) return fail(h, BRISK_HIP_EUNSUPPORTED, "scan state does not fit LDS");
             h->scan_waves = wv;
             h->scan_lds = fixed + wv * per_wave;
-            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
             const char* v1 = getenv("BRISK_SCAN_V1");
             h->scan_v1 = v1 && v1[0] == '1';
         }

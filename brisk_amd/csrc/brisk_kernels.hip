@@ -305,11 +305,20 @@ struct ScanCfg {
 };
 
 // class from chunk tables: tabs[c][v] (R) and tabs[nch+c][v] (R of the rotation)
+template <int NCH>  // NCH > 0: compile-time chunk count (unrolled lookups); 0: runtime nch
 __device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const double* tabs, const double* coef) {
     double r = 0.0, rr = 0.0;
-    for (u32 c = 0; c < nch; c++) {
-        r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
-        rr += tabs[(nch + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
+    if (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+            rr += tabs[(NCH + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
+        }
+    } else {
+        for (u32 c = 0; c < nch; c++) {
+            r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+            rr += tabs[(nch + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
+        }
     }
     const double eps = 0.000001, g = 1e-9;
     // any summation order is within ~1e-13 of the reference's fold; inside the guard band redo it exactly
@@ -318,8 +327,9 @@ __device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const doub
     if (r < -eps) return rr > -eps ? 1u : 2u;
     return 2u;
 }
+template <int NCH = 0>
 __device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, const double* tabs, const double* coef) {
-    return ((u64)decy_class_fast(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
+    return ((u64)decy_class_fast<NCH>(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
 }
 
 __global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, const double* __restrict__ g_tabs, const u64* __restrict__ x, u64 n,
@@ -360,6 +370,7 @@ __device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first
     }
 }
 
+template <int NCH>
 __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
                                                 u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, int query_mode) {
     extern __shared__ double smem_d[];
@@ -391,7 +402,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         max_nk = y > max_nk ? y : max_nk;
     }
     if (max_nk == 0) return;
-    const u64 KEY0 = order_key_fast(0, m, M, nch, s_tabs, s_coef);
+    const u64 KEY0 = order_key_fast<NCH>(0, m, M, nch, s_tabs, s_coef);
 
     // ---- prologue: candidate state just before step -R_init, then R_init steps into the ring
     const u32 Ri = cfg.R_init, R = cfg.R;
@@ -410,7 +421,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         cf = ((cf << 2) + c) & M;
         cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
         const bool revf = cr < cf;
-        ring[slot] = order_key_fast(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
+        ring[slot] = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
         revhist = (revhist << 1) | (revf ? 1ull : 0ull);
         slot = slot + 1 == R ? 0 : slot + 1;
     }
@@ -429,13 +440,14 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             u64 key;
             bool rv;
             if (i + m <= cfg.nlow1) {  // inside the low 64 bits: the key of step -1-i
-                key = ring[(slot + R - 1 - i) % R];
+                const u32 tsl = slot + R - 1 - i;  // < 2R
+                key = ring[tsl >= R ? tsl - R : tsl];
                 rv = (revhist >> i) & 1;
             } else if (i < cfg.nlow1) {  // zero-padded window (F2)
                 const u64 fwd = (low64 >> (2 * i)) & M;
                 const u64 rcv = rc64(fwd, m);
                 rv = rcv < fwd;
-                key = order_key_fast(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+                key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
             } else {  // beyond the low 64 bits: the all-A m-mer
                 key = KEY0;
                 rv = false;
@@ -480,7 +492,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
         low64 = (low64 << 2) | c;
         const bool revf = cr < cf;
-        const u64 h = order_key_fast(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
+        const u64 h = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
         revhist = (revhist << 1) | (revf ? 1ull : 0ull);
         ring[slot] = h;
         const u32 cur_slot = slot;
@@ -517,7 +529,8 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             bool rv = false;
             if (lane <= Km) {
                 if (lane + m <= cfg.nlow) {
-                    key = wbase[(u32)L * cfg.pitch + (cur_slot + R - lane) % R];
+                    const u32 tsl = cur_slot + R - lane;  // < 2R
+                    key = wbase[(u32)L * cfg.pitch + (tsl >= R ? tsl - R : tsl)];
                     rv = (rhL >> lane) & 1;
                 } else if (lane >= cfg.nlow) {
                     key = KEY0;
@@ -530,7 +543,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
                     const u64 fwd = (lowL >> (2 * (lane & 31))) & M;
                     const u64 rcv = rc64(fwd, m);
                     const bool rv2 = rcv < fwd;
-                    const u64 k2 = order_key_fast(rv2 ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+                    const u64 k2 = order_key_fast<NCH>(rv2 ? rcv : fwd, m, M, nch, s_tabs, s_coef);
                     if (fake) {
                         key = k2;
                         rv = rv2;
