@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--part-bits", type=int, default=0, help="log2(#partitions); 0: library default")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--verify", action="store_true", help="after timing, check a property of the result")
     args = ap.parse_args()
 
@@ -67,10 +69,15 @@ def main():
         args.gpus = world
     N = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # --backend gloo + --share-gpu: rehearsal of the N>1 flow with every rank on cuda:0
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if N > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     k, m, b, L = args.k, args.m, args.b, args.read_len
     n_reads = args.reads
@@ -89,58 +96,24 @@ def main():
     with torch.cuda.stream(stream):
         d_packed = torch.zeros((n_reads * L + 15) // 16 + 4, dtype=torch.int32, device=dev)
         d_starts = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
-    gen = brisk_amd.BriskHip(k, m, b, device=local_rank, stream=sptr, part_bits=2)
+    gen = brisk_amd.BriskHip(k, m, b, device=dev_index, stream=sptr, part_bits=2)
     stream.synchronize()
     gen.synth_reads(genome_len, rank * n_reads, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())
     gen.sync()
     gen.close()
 
-    W = None
-    scratch = {}
-
     # one handle for the whole run: every step starts from brisk_hip_clear(), i.e. an
     # empty index whose device memory is already reserved (the allocator, not the path)
-    ix = brisk_amd.BriskHip(k, m, b, device=local_rank, stream=sptr, owner_rank=rank, n_owners=N, part_bits=args.part_bits)
+    from brisk_amd.exchange import ShardedCounter
+    sc = ShardedCounter(k, m, b, rank, N, dev_index, stream, part_bits=args.part_bits)
+    ix = sc.ix
 
     def one_job(profile):
         """empty index + the whole hot path over this rank's reads"""
-        nonlocal W
         ix.clear()
         ix.profile_enable(profile)
-        if N == 1:
-            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
-        else:
-            W = ix.record_words
-            with torch.cuda.stream(stream):
-                cap = scratch.get("cap", n_reads * 6 + 4096)
-                while True:
-                    if scratch.get("rec") is None or scratch["rec"].numel() < cap * W:
-                        scratch["rec"] = torch.empty(cap * W, dtype=torch.int64, device=dev)
-                        scratch["out"] = torch.empty(cap * W, dtype=torch.int64, device=dev)
-                    try:
-                        n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, scratch["rec"].data_ptr(), cap)
-                        break
-                    except brisk_amd.BriskHipError as e:
-                        if e.code != 5:
-                            raise
-                        cap = ix.scan_bound(d_starts.data_ptr(), n_reads)
-                scratch["cap"] = cap
-                counts = ix.route_records(scratch["rec"].data_ptr(), n_rec, scratch["out"].data_ptr())
-                send = torch.from_numpy(counts.astype(np.int64)).to(dev)
-                recv = torch.empty_like(send)
-                dist.all_to_all_single(recv, send)  # counts first
-                recv_counts = recv.cpu().tolist()
-                n_in = int(sum(recv_counts))
-                if scratch.get("inbox") is None or scratch["inbox"].numel() < n_in * W:
-                    scratch["inbox"] = torch.empty(int(n_in * 1.1) * W + W, dtype=torch.int64, device=dev)
-                inbox = scratch["inbox"][: n_in * W]
-                dist.all_to_all_single(inbox, scratch["out"][: n_rec * W],
-                                       output_split_sizes=[c * W for c in recv_counts],
-                                       input_split_sizes=[int(c) * W for c in counts])  # then the payload
-                stream.synchronize()
-                ix.insert_records(inbox.data_ptr(), n_in)
+        sc.count_packed(d_packed, d_starts, n_reads)
         ix.sync()
-        return ix
 
     def run_steps(nsteps, profile):
         entries = 0

@@ -764,9 +764,8 @@ BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_reco
     if ((rc = prefix_partitions(h, no))) return rc;
     {
         ProfScope ps(h, S_SCATTER);
-        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_cur32, d_out, 1,
-                           (const u32*)nullptr, (u32*)nullptr);
-        if ((rc = launch_check(h, "k_scatter(owner)"))) return rc;
+        hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_cur32, d_out);
+        if ((rc = launch_check(h, "k_owner_scatter"))) return rc;
     }
     std::vector<u32> off(no + 1);
     HIPCHK(h, hipMemcpyAsync(off.data(), h->d_off, ((u64)no + 1) * 4, hipMemcpyDeviceToHost, h->stream));

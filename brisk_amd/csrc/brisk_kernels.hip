@@ -744,13 +744,56 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
 // ===========================================================================
 // k_scatter: bucket radix -- move each record to its partition's slice.
 // owner mode (n_owners > 1 and by_owner): the bins are owners instead of partitions.
+// Owner routing has only n_owners (<= 64) bins: lanes of a wave that share an owner are
+// counted / ranked with ballots, so each wave issues ONE atomic per owner it holds
+// instead of 64 on the same address.
+__device__ __forceinline__ u32 owner_of_record(const BriskParams& P, u64 hdr) {
+    return (u32)(((u64)(hdr_bucket(hdr) >> P.shift) * P.n_owners) >> P.part_bits);
+}
 __global__ void __launch_bounds__(256) k_owner_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, unsigned long long* __restrict__ hist) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rec) return;
-    const u64 hdr = rec[i * P.stride + P.nw];
-    const u32 part = hdr_bucket(hdr) >> P.shift;
-    const u32 owner = (u32)(((u64)part * P.n_owners) >> P.part_bits);
-    atomicAdd(&hist[owner], 1ull | ((unsigned long long)hdr_n(hdr) << 32));
+    const bool ok = i < n_rec;
+    u64 hdr = 0;
+    if (ok) hdr = rec[i * P.stride + P.nw];
+    const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+    const u32 lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const u32 o = __shfl(owner, lead, 64);
+        const unsigned long long same = __ballot(owner == o);
+        // records and k-mer instances of this owner in the wave
+        u32 inst = owner == o ? hdr_n(hdr) : 0;
+        for (int d = 32; d > 0; d >>= 1) inst += __shfl_xor(inst, d, 64);
+        if ((int)lane == lead) atomicAdd(&hist[o], (unsigned long long)__popcll(same) | ((unsigned long long)inst << 32));
+        todo &= ~same;
+    }
+}
+__global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u32* __restrict__ cursor,
+                                                       u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < n_rec;
+    const u64* src = rec + i * P.stride;
+    u64 hdr = 0;
+    if (ok) hdr = src[P.nw];
+    const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+    const u32 lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(ok);
+    u32 slot = 0;
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const u32 o = __shfl(owner, lead, 64);
+        const unsigned long long same = __ballot(owner == o);
+        u32 base = 0;
+        if ((int)lane == lead) base = atomicAdd(&cursor[o], (u32)__popcll(same));
+        base = __shfl(base, lead, 64);
+        if (owner == o) slot = base + (u32)__popcll(same & lanes_below(lane));
+        todo &= ~same;
+    }
+    if (ok) {
+        u64* dst = out + (u64)slot * P.stride;
+        for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
+    }
 }
 __global__ void __launch_bounds__(256) k_part_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, unsigned long long* __restrict__ hist) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,96 @@
+"""Bucket-range sharding across the GPUs of one node.
+
+One process per GPU.  Every rank scans its own reads; super-k-mer records are
+binned by the owner of their bucket range and exchanged with ONE all-to-all
+(counts first, then the payload) over torch.distributed -- backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" on CPU for tests.  There is no other collective on the
+data path.  The reference is single-process; nothing here has a counterpart in it.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def owner_of_bucket(bucket, b: int, part_bits: int, n_owners: int):
+    """Owner rank of a bucket id: partitions (contiguous bucket ranges) are dealt in
+    contiguous blocks, owner = partition * N >> part_bits.  Mirrors k_owner_hist /
+    k_scatter in csrc/brisk_kernels.hip; works on ints and numpy arrays."""
+    shift = 2 * b - part_bits
+    part = bucket >> shift
+    return (part * n_owners) >> part_bits
+
+
+def exchange_records(send: torch.Tensor, send_counts, words: int, group=None,
+                     inbox: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, List[int]]:
+    """send: int64 tensor of records grouped by destination rank (rank 0 first),
+    send_counts[r] records of `words` int64 each for rank r.  Returns (inbox, recv_counts):
+    the records this rank owns, grouped by source rank."""
+    world = dist.get_world_size(group)
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices):
+        # stage through host memory; the production path below never leaves the device
+        n_out = int(sum(int(c) for c in send_counts))
+        host_in, recv_counts = exchange_records(send[: n_out * words].cpu(), send_counts, words, group, None)
+        n_in = sum(recv_counts)
+        if inbox is None or inbox.numel() < n_in * words:
+            inbox = torch.empty(max(n_in, 1) * words, dtype=torch.int64, device=send.device)
+        inbox[: n_in * words].copy_(host_in[: n_in * words])
+        return inbox, recv_counts
+    sc = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=send.device)
+    assert sc.numel() == world
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)  # counts first
+    recv_counts = [int(v) for v in rc.cpu().tolist()]
+    n_in = sum(recv_counts)
+    if inbox is None or inbox.numel() < n_in * words:
+        inbox = torch.empty(max(n_in, 1) * words, dtype=torch.int64, device=send.device)
+    view = inbox[: n_in * words]
+    n_out = int(sum(int(c) for c in send_counts))
+    dist.all_to_all_single(view, send[: n_out * words],
+                           output_split_sizes=[c * words for c in recv_counts],
+                           input_split_sizes=[int(c) * words for c in send_counts], group=group)  # then the payload
+    return inbox, recv_counts
+
+
+class ShardedCounter:
+    """A rank's share of a k-mer counting job: owns the buckets of its partition range."""
+
+    def __init__(self, k: int, m: int, b: int, rank: int, world: int, device: int, stream: torch.cuda.Stream,
+                 part_bits: int = 0, group=None):
+        import brisk_amd
+        self.rank, self.world, self.group, self.stream = rank, world, group, stream
+        self.dev = torch.device("cuda", device)
+        self.ix = brisk_amd.BriskHip(k, m, b, device=device, stream=stream.cuda_stream, owner_rank=rank, n_owners=world,
+                                     part_bits=part_bits)
+        self.W = self.ix.record_words
+        self._rec = self._out = self._inbox = None
+        self._cap = 0
+
+    def count_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> None:
+        ix, W = self.ix, self.W
+        if self.world == 1:
+            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
+            return
+        import brisk_amd
+        with torch.cuda.stream(self.stream):
+            cap = self._cap or (n_reads * 6 + 4096)
+            while True:
+                if self._rec is None or self._rec.numel() < cap * W:
+                    self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
+                    self._out = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
+                try:
+                    n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, self._rec.data_ptr(), cap)
+                    break
+                except brisk_amd.BriskHipError as e:
+                    if e.code != brisk_amd.hipapi.ECAPACITY:
+                        raise
+                    cap = ix.scan_bound(d_starts.data_ptr(), n_reads)
+            self._cap = cap
+            counts = ix.route_records(self._rec.data_ptr(), n_rec, self._out.data_ptr())
+            self._inbox, recv_counts = exchange_records(self._out, counts, W, self.group, self._inbox)
+            self.stream.synchronize()
+            ix.insert_records(self._inbox.data_ptr(), sum(recv_counts))

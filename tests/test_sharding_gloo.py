@@ -1,0 +1,94 @@
+"""world_size-2 gloo test of the N>1 path (runs on CPU): the owner arithmetic, the
+record exchange (counts, then payload, one all-to-all) and the record format.  The
+per-rank device work is replaced here by the oracle's record generator -- the same
+records the scan kernel is checked against in tests/test_gpu_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _records_for(O, h, reads, k, m, b):
+    W = int(O.lib.bo_record_words(k, m, b)) + 1
+    rows = []
+    for s in reads:
+        c, bucket, n, idx0 = O.records(h, s, k, m, b)
+        for i in range(len(n)):
+            hdr = int(bucket[i]) | (int(n[i]) << 32) | (int(idx0[i]) << 40)
+            rows.append([int(x) for x in c[i]] + [hdr])
+    return np.array(rows, dtype=np.uint64).reshape(-1, W), W
+
+
+def _expand(rec, W, k, b):
+    """records -> set-like list of (bucket, compacted k-mer, idx') with multiplicity"""
+    out = []
+    kb = k - b
+    for r in rec:
+        big = sum(int(w) << (64 * i) for i, w in enumerate(r[: W - 1]))
+        hdr = int(r[W - 1])
+        bucket, n, idx0 = hdr & 0xffffffff, (hdr >> 32) & 0xff, (hdr >> 40) & 0xff
+        for j in range(n):
+            out.append((bucket, (big >> (2 * (n - 1 - j))) & ((1 << (2 * kb)) - 1), idx0 + j))
+    return out
+
+
+def _worker(rank, world, port, k, m, b, part_bits, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from brisk_amd.exchange import exchange_records, owner_of_bucket
+    O = oracle.Oracle()
+    reads = [bytes(r) for r in O.synth_reads(6000, 0, 600)]
+    mine = reads[rank::world]
+    h = O.index_new(k, m, b)
+    rec, W = _records_for(O, h, mine, k, m, b)
+    O.index_free(h)
+    owner = owner_of_bucket((rec[:, W - 1] & np.uint64(0xffffffff)).astype(np.int64), b, part_bits, world)
+    order = np.argsort(owner, kind="stable")
+    counts = np.bincount(owner, minlength=world)
+    send = torch.from_numpy(rec[order].astype(np.int64).reshape(-1))
+    inbox, recv_counts = exchange_records(send, counts, W)
+    got = inbox[: sum(recv_counts) * W].numpy().view(np.uint64).reshape(-1, W)
+    got_owner = owner_of_bucket((got[:, W - 1] & np.uint64(0xffffffff)).astype(np.int64), b, part_bits, world)
+    q.put((rank, len(rec), [int(c) for c in counts], recv_counts, bool((got_owner == rank).all()), _expand(got, W, k, b)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,m,b,part_bits", [(63, 21, 14, 24), (31, 11, 4, 8)])
+def test_two_rank_exchange_matches_oracle(O, k, m, b, part_bits):
+    import oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, m, b, part_bits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # conservation: what rank s sent to rank r is what r received from s
+    for r in range(world):
+        assert res[r][3] == [res[s][2][r] for s in range(world)]
+        assert res[r][4], "a rank received a record it does not own"
+    assert sum(sum(x[3]) for x in res) == sum(x[1] for x in res)
+    # the union of the shards' k-mers, counted, equals the oracle's whole-job multiset
+    from collections import Counter
+    shards = [Counter(x[5]) for x in res]
+    assert not (set(shards[0]) & set(shards[1])), "a k-mer landed on two owners"
+    total = shards[0] + shards[1]
+    reads = [bytes(r) for r in O.synth_reads(6000, 0, 600)]
+    lines, nk, nb = O.count(reads, k, m, b)
+    assert len(total) == nk
+    assert sorted(c % 256 for c in total.values()) == sorted(int(l.split()[2]) for l in lines)
+    assert len({key[0] for key in total}) == nb
