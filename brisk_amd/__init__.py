@@ -6,4 +6,4 @@ Python package is a thin ctypes view of the C-ABI used by tests, ``bench.py``
 and ``__graft_entry__``; it never computes anything itself and raises if the
 library is missing (there is no CPU fallback).
 """
-from .hipapi import BriskHip, BriskHipError, build_library, library_path, coef_table  # noqa: F401
+from .hipapi import BriskHip, BriskHipError, build_apps, build_library, library_path, coef_table  # noqa: F401

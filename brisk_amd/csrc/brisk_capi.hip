@@ -47,6 +47,9 @@ struct brisk_hip_index {
     u32 scan_waves = 0;         // waves per k_scan2 block
     size_t scan_lds = 0;
     bool scan_v1 = false;       // BRISK_SCAN_V1=1: the plain restatement kernel
+    bool entry_ids = false;
+    unsigned long long* d_id_counter = nullptr;
+    DevBuf seq_buf;
     // the index
     u64 arena_cap = 0;
     u64 arena_used_host = 0;
@@ -135,23 +138,30 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
     ncap = std::max<u64>(ncap, 1u << 16);
     u64* nk = nullptr;
     uint8_t* nc = nullptr;
+    u32* ni = nullptr;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMalloc((void**)&nk, ncap * 16));
     hipError_t e = hipMalloc((void**)&nc, ncap);
+    if (e == hipSuccess && h->entry_ids) e = hipMalloc((void**)&ni, ncap * 4);
     if (e != hipSuccess) {
         hipFree(nk);
+        if (nc) hipFree(nc);
         return fail(h, BRISK_HIP_ENOMEM, "arena growth: out of device memory");
     }
     if (h->arena_used_host) {
         HIPCHK(h, hipMemcpyAsync(nk, h->ix.keys, h->arena_used_host * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(nc, h->ix.counts, h->arena_used_host, hipMemcpyDeviceToDevice, h->stream));
+        if (ni) HIPCHK(h, hipMemcpyAsync(ni, h->ix.ids, h->arena_used_host * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     if (h->ix.keys) hipFree(h->ix.keys);
     if (h->ix.counts) hipFree(h->ix.counts);
+    if (h->ix.ids) hipFree(h->ix.ids);
     h->ix.keys = nk;
     h->ix.counts = nc;
+    h->ix.ids = ni;
     h->arena_cap = ncap;
+    h->ix.arena_cap = ncap;
     return BRISK_HIP_OK;
 }
 
@@ -221,13 +231,13 @@ int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
 
 // scan reads -> records in d_rec (cap records).  n_rec_out on host after a sync.
 int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, u64* d_rec, u64 cap, bool with_hist,
-              bool query_mode, u32* d_tags, u64* n_rec_out) {
+              bool query_mode, u32* d_tags, u64* n_rec_out, u64* d_ret = nullptr) {
     if (with_hist) HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
-    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags};
+    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret};
     {
         ProfScope ps(h, S_SCAN);
-        if (h->scan_v1) {
+        if (h->scan_v1 || d_ret) {  // sequence mode needs the minimizer values: the plain kernel carries them
             hipLaunchKernelGGL(k_scan, dim3(nblocks(n_reads, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_reads,
                                h->d_coef, out, query_mode ? 1 : 0);
         } else {
@@ -382,6 +392,9 @@ void free_all(brisk_hip_index* h) {
     fr(h->d_tabs);
     fr(h->ix.keys);
     fr(h->ix.counts);
+    fr(h->ix.ids);
+    fr(h->d_id_counter);
+    fr(h->seq_buf.p);
     fr(h->ix.dir);
     fr(h->ix.cursor);
     fr(h->ix.bucket_bits);
@@ -417,7 +430,8 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     *out = nullptr;
     // Parameters contract (parameters.hpp:19-22, Brisk.hpp:50-51, counter.cpp:32)
     if (!(b >= 1 && b <= m && m < k && k <= 63 && (m & 1) && m <= 31) || !coef_table) return BRISK_HIP_EINVAL;
-    if (data_bytes != 1) return BRISK_HIP_EUNSUPPORTED;
+    if (b > 16) return BRISK_HIP_EUNSUPPORTED;  // bucket ids are 32-bit, as the reference's uint32_t directory (DenseMenuYo.hpp:37,105)
+    if (data_bytes != 1 && !(opt && opt->struct_size >= sizeof(brisk_hip_options) && opt->entry_ids)) return BRISK_HIP_EUNSUPPORTED;
     brisk_hip_options o{};
     if (opt) memcpy(&o, opt, std::min<size_t>(opt->struct_size ? opt->struct_size : sizeof(o), sizeof(o)));
     int ndev = 0;
@@ -449,6 +463,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     h->n_parts = 1ull << P.part_bits;
     h->n_buckets = 1ull << (2 * b);
     h->max_batch_reads = o.max_batch_reads ? o.max_batch_reads : (1ull << 26);
+    h->entry_ids = o.entry_ids != 0;
     h->device = o.device;
 
     auto init = [&]() -> int {
@@ -520,6 +535,8 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMalloc((void**)&h->d_touched, np * 4));
         h->n_scan_blocks = nblocks(np, 256 * SCAN_ITEMS);
         HIPCHK(h, hipMalloc((void**)&h->d_block_sums, (size_t)(h->n_scan_blocks + 1) * 4));
+        HIPCHK(h, hipMalloc((void**)&h->d_id_counter, 8));
+        HIPCHK(h, hipMemsetAsync(h->d_id_counter, 0, 8, h->stream));
         HIPCHK(h, hipMalloc((void**)&h->d_small, 64));
         HIPCHK(h, hipHostMalloc((void**)&h->h_small, 64));
         HIPCHK(h, hipMemsetAsync(h->d_small, 0, 64, h->stream));
@@ -556,6 +573,7 @@ BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
     const u64 np = h->n_parts;
     HIPCHK(h, hipMemsetAsync(h->ix.dir, 0, np * sizeof(DirEnt), h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_id_counter, 0, 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.slot_cur, 0, INSERT_SLOTS * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.slot_end, 0, INSERT_SLOTS * 8, h->stream));
@@ -591,6 +609,7 @@ BRISK_API int brisk_hip_get_layout(const brisk_hip_index* h, brisk_hip_layout* o
 BRISK_API int brisk_hip_insert_packed(brisk_hip_index* h, const uint32_t* d_packed, const uint64_t* d_starts, uint64_t n_reads) {
     if (!h || (n_reads && (!d_packed || !d_starts))) return BRISK_HIP_EINVAL;
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "insert_packed on a sharded index: use scan/route/insert_records");
+    if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
     return insert_packed_impl(h, d_packed, d_starts, n_reads);
 }
@@ -598,6 +617,7 @@ BRISK_API int brisk_hip_insert_packed(brisk_hip_index* h, const uint32_t* d_pack
 BRISK_API int brisk_hip_insert_reads(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads) {
     if (!h || (n_reads && (!bases || !offsets))) return BRISK_HIP_EINVAL;
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "insert_reads on a sharded index: use scan/route/insert_records");
+    if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
     return for_each_host_batch(h, bases, offsets, n_reads, [&](u64, u64 nr) {
         return insert_packed_impl(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, nr);
@@ -636,7 +656,7 @@ BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, cons
     HIPCHK(h, hipMemcpyAsync(d_idx, minimizer_idx, n, hipMemcpyHostToDevice, h->stream));
     {
         ProfScope ps(h, S_LOOKUP);
-        hipLaunchKernelGGL(k_lookup, dim3(nblocks(n * 64, 256)), dim3(256), 0, h->stream, h->P, h->ix, d_lo, d_hi, d_idx, n, d_data, d_found);
+        hipLaunchKernelGGL(k_lookup, dim3(nblocks(n * 64, 256)), dim3(256), 0, h->stream, h->P, h->ix, d_lo, d_hi, d_idx, n, d_data, d_found, (u32*)nullptr);
         if ((rc = launch_check(h, "k_lookup"))) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(out_data, d_data, n, hipMemcpyDeviceToHost, h->stream));
@@ -645,9 +665,10 @@ BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, cons
     return BRISK_HIP_OK;
 }
 
-BRISK_API int brisk_hip_enumerate(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo, uint64_t* out_hi, uint8_t* out_minimizer_idx,
-                                  uint8_t* out_data, uint64_t cap, uint64_t* n_out) {
-    if (!h || !cursor || !n_out || (cap && (!out_lo || !out_hi || !out_minimizer_idx || !out_data))) return BRISK_HIP_EINVAL;
+static int enumerate_impl(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo, uint64_t* out_hi, uint8_t* out_minimizer_idx,
+                          uint8_t* out_data, uint32_t* out_ids, uint64_t cap, uint64_t* n_out) {
+    if (!h || !cursor || !n_out || (cap && (!out_lo || !out_hi || !out_minimizer_idx))) return BRISK_HIP_EINVAL;
+    if (out_ids && !h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "not an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
     *n_out = 0;
     if (*cursor == 0 || !h->dir_snapshot_valid) {
@@ -671,27 +692,41 @@ BRISK_API int brisk_hip_enumerate(brisk_hip_index* h, uint64_t* cursor, uint64_t
     if (q == p) return fail(h, BRISK_HIP_ECAPACITY, "enumerate: cap smaller than one partition");
     const u64 np = q - p;
     int rc;
-    if ((rc = ensure(h, h->enum_out, np * 8 + total * 18 + 64))) return rc;
+    if ((rc = ensure(h, h->enum_out, np * 8 + total * 22 + 64))) return rc;
     char* b0 = (char*)h->enum_out.p;
     u64* d_base = (u64*)b0;
     u64* d_lo = (u64*)(b0 + np * 8);
     u64* d_hi = d_lo + total;
-    uint8_t* d_idx = (uint8_t*)(d_hi + total);
+    u32* d_ids = out_ids ? (u32*)(d_hi + total) : nullptr;
+    uint8_t* d_idx = (uint8_t*)(d_hi + total) + total * 4;
     uint8_t* d_cnt = d_idx + total;
     HIPCHK(h, hipMemcpyAsync(d_base, base.data(), np * 8, hipMemcpyHostToDevice, h->stream));
     if (total) {
         ProfScope ps(h, S_ENUM);
-        hipLaunchKernelGGL(k_enumerate, dim3((u32)np), dim3(64), 0, h->stream, h->P, h->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt);
+        hipLaunchKernelGGL(k_enumerate, dim3((u32)np), dim3(64), 0, h->stream, h->P, h->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt, d_ids);
         if ((rc = launch_check(h, "k_enumerate"))) return rc;
         HIPCHK(h, hipMemcpyAsync(out_lo, d_lo, total * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(out_hi, d_hi, total * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(out_minimizer_idx, d_idx, total, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(out_data, d_cnt, total, hipMemcpyDeviceToHost, h->stream));
+        if (out_data) HIPCHK(h, hipMemcpyAsync(out_data, d_cnt, total, hipMemcpyDeviceToHost, h->stream));
+        if (out_ids) HIPCHK(h, hipMemcpyAsync(out_ids, d_ids, total * 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *cursor = q;
     *n_out = total;
     return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_enumerate(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo, uint64_t* out_hi, uint8_t* out_minimizer_idx,
+                                  uint8_t* out_data, uint64_t cap, uint64_t* n_out) {
+    if (cap && !out_data) return BRISK_HIP_EINVAL;
+    return enumerate_impl(h, cursor, out_lo, out_hi, out_minimizer_idx, out_data, nullptr, cap, n_out);
+}
+
+BRISK_API int brisk_hip_enumerate_ids(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo, uint64_t* out_hi, uint8_t* out_minimizer_idx,
+                                      uint32_t* out_ids, uint64_t cap, uint64_t* n_out) {
+    if (cap && !out_ids) return BRISK_HIP_EINVAL;
+    return enumerate_impl(h, cursor, out_lo, out_hi, out_minimizer_idx, nullptr, out_ids, cap, n_out);
 }
 
 BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t* nb_skmers, uint64_t* nb_kmers, uint64_t* memory_bytes,
@@ -777,7 +812,143 @@ BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_reco
 BRISK_API int brisk_hip_insert_records(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records) {
     if (!h || (n_records && !d_records)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     return insert_records_impl(h, d_records, n_records, false);
+}
+
+// ---- the per-call API under the C++ facade ----------------------------------------
+BRISK_API int brisk_hip_scan_sequence(brisk_hip_index* h, const char* bases, uint64_t len, uint64_t cap_kmers, uint64_t* skm_ret, uint32_t* skm_n,
+                                      uint64_t* km_lo, uint64_t* km_hi, uint8_t* km_idx, uint64_t* n_skm) {
+    if (!h || !n_skm) return BRISK_HIP_EINVAL;
+    *n_skm = 0;
+    if (len < h->P.k) return BRISK_HIP_OK;
+    const u64 nk = len - h->P.k + 1;
+    if (!bases || !skm_ret || !skm_n || !km_lo || !km_hi || !km_idx || cap_kmers < nk) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint64_t offs[2] = {0, len};
+    const BriskParams& P = h->P;
+    const u32 row = P.w + 1;
+    return for_each_host_batch(h, bases, offs, 1, [&](u64, u64) -> int {
+        int rc;
+        // worst case one vector per k-mer
+        if ((rc = ensure(h, h->staging, nk * P.stride * 8))) return rc;
+        if ((rc = ensure(h, h->tags_a, nk * 4))) return rc;
+        if ((rc = ensure(h, h->seq_buf, nk * 8 + nk * (size_t)row * 17))) return rc;
+        u64* d_ret = (u64*)h->seq_buf.p;
+        u64* d_lo = d_ret + nk;
+        u64* d_hi = d_lo + nk * row;
+        uint8_t* d_idx = (uint8_t*)(d_hi + nk * row);
+        u64 n_rec = 0;
+        if ((rc = scan_impl(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, 1, (u64*)h->staging.p, nk, false, false, (u32*)h->tags_a.p,
+                            &n_rec, d_ret)))
+            return rc;
+        if (!n_rec) return BRISK_HIP_OK;
+        hipLaunchKernelGGL(k_expand_records, dim3((u32)n_rec), dim3(64), 0, h->stream, P, (const u64*)h->staging.p, (u32)n_rec, row, d_lo, d_hi, d_idx);
+        if ((rc = launch_check(h, "k_expand_records"))) return rc;
+        std::vector<u64> rec(n_rec * P.stride), ret(n_rec), lo(n_rec * row), hi(n_rec * row);
+        std::vector<u32> pos(n_rec);
+        std::vector<uint8_t> idx(n_rec * row);
+        HIPCHK(h, hipMemcpyAsync(rec.data(), h->staging.p, rec.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(ret.data(), d_ret, n_rec * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(pos.data(), h->tags_a.p, n_rec * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(lo.data(), d_lo, lo.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(hi.data(), d_hi, hi.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(idx.data(), d_idx, idx.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        // vectors come back in no particular order: next() hands them out by position in the sequence
+        std::vector<u32> order(n_rec);
+        for (u32 i = 0; i < n_rec; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return pos[a] < pos[b]; });
+        u64 at = 0;
+        for (u64 o = 0; o < n_rec; o++) {
+            const u32 r = order[o];
+            const u32 n = (u32)(rec[(u64)r * P.stride + P.nw] >> 32) & 0xff;
+            skm_ret[o] = ret[r];
+            skm_n[o] = n;
+            for (u32 j = 0; j < n; j++, at++) {
+                km_lo[at] = lo[(u64)r * row + j];
+                km_hi[at] = hi[(u64)r * row + j];
+                km_idx[at] = idx[(u64)r * row + j];
+            }
+        }
+        *n_skm = n_rec;
+        return BRISK_HIP_OK;
+    });
+}
+
+static int upload_queries(brisk_hip_index* h, const uint64_t* lo, const uint64_t* hi, const uint8_t* idx, u64 n, u64** d_lo, u64** d_hi,
+                          uint8_t** d_idx, u32** d_ids, uint8_t** d_new) {
+    int rc;
+    if ((rc = ensure(h, h->lookup_buf, n * 22 + 64))) return rc;
+    char* base = (char*)h->lookup_buf.p;
+    *d_lo = (u64*)base;
+    *d_hi = (u64*)(base + n * 8);
+    *d_ids = (u32*)(base + n * 16);
+    *d_idx = (uint8_t*)(base + n * 20);
+    *d_new = *d_idx + n;
+    HIPCHK(h, hipMemcpyAsync(*d_lo, lo, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(*d_hi, hi, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(*d_idx, idx, n, hipMemcpyHostToDevice, h->stream));
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_upsert_kmers(brisk_hip_index* h, const uint64_t* kmer_lo, const uint64_t* kmer_hi, const uint8_t* minimizer_idx, uint64_t n,
+                                     uint32_t* ids, uint8_t* newly) {
+    if (!h || (n && (!kmer_lo || !kmer_hi || !minimizer_idx || !ids || !newly)) || n > 255) return BRISK_HIP_EINVAL;
+    if (!h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "not an entry-id index");
+    if (!n) return BRISK_HIP_OK;
+    for (u64 i = 0; i < n; i++)
+        if (minimizer_idx[i] > h->P.w) return fail(h, BRISK_HIP_EINVAL, "minimizer_idx > k-m");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (!h->arena_cap && (rc = ensure_arena(h, 1u << 16))) return rc;
+    u64 *d_lo, *d_hi;
+    uint8_t *d_idx, *d_new;
+    u32* d_ids;
+    if ((rc = upload_queries(h, kmer_lo, kmer_hi, minimizer_idx, n, &d_lo, &d_hi, &d_idx, &d_ids, &d_new))) return rc;
+    u32 done = 0;
+    while (done < n) {
+        hipLaunchKernelGGL(k_upsert, dim3(1), dim3(64), 0, h->stream, h->P, h->ix, d_lo + done, d_hi + done, d_idx + done, (u32)(n - done),
+                           d_ids + done, d_new + done, h->d_id_counter, (u32*)(h->d_small + 7));
+        if ((rc = launch_check(h, "k_upsert"))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const u32 step = (u32)h->h_small[7];
+        done += step;
+        h->arena_used_host = h->h_small[5];
+        if (done < n) {  // the arena is full: double it and go on with the rest of the vector
+            if ((rc = ensure_arena(h, h->arena_cap))) return rc;
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(newly, d_new, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->nb_skmers += 1;
+    h->dir_snapshot_valid = false;
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_find_kmers(brisk_hip_index* h, const uint64_t* kmer_lo, const uint64_t* kmer_hi, const uint8_t* minimizer_idx, uint64_t n,
+                                   uint32_t* ids) {
+    if (!h || (n && (!kmer_lo || !kmer_hi || !minimizer_idx || !ids))) return BRISK_HIP_EINVAL;
+    if (!h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "not an entry-id index");
+    if (!n) return BRISK_HIP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    u64 *d_lo, *d_hi;
+    uint8_t *d_idx, *d_new;
+    u32* d_ids;
+    if ((rc = upload_queries(h, kmer_lo, kmer_hi, minimizer_idx, n, &d_lo, &d_hi, &d_idx, &d_ids, &d_new))) return rc;
+    if (!h->arena_cap) {
+        for (u64 i = 0; i < n; i++) ids[i] = 0xffffffffu;
+        return BRISK_HIP_OK;
+    }
+    hipLaunchKernelGGL(k_lookup, dim3(nblocks(n * 64, 256)), dim3(256), 0, h->stream, h->P, h->ix, d_lo, d_hi, d_idx, n, d_new, d_new, d_ids);
+    if ((rc = launch_check(h, "k_lookup(ids)"))) return rc;
+    HIPCHK(h, hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BRISK_HIP_OK;
 }
 
 // ---- helpers ------------------------------------------------------------------

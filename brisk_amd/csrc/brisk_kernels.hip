@@ -111,7 +111,8 @@ struct ScanOut {
     unsigned long long* n_rec;   // record cursor
     unsigned long long* hist;    // per partition: low 32 records, high 32 k-mer instances (may be null)
     u32* overflow;
-    u32* tag;                    // query mode: read index per record (may be null)
+    u32* tag;                    // query mode: read index per record; sequence mode: position of the first k-mer (may be null)
+    u64* ret;                    // sequence mode: the minimizer value next() returns with the vector (may be null)
 };
 
 struct MiniState {
@@ -171,7 +172,7 @@ __device__ MiniState rescan_minimizer(const u32* __restrict__ packed, u64 q, u32
 // [p0, p0+n), vector reversed if `rev` (Kmers.cpp:554-556,597-599); idx_end is
 // the minimizer_idx of the LAST element of the returned vector.
 __device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
-                            u32 idx_end, const ScanOut& out, u32 tag) {
+                            u32 idx_end, const ScanOut& out, u32 tag, u64 ret = 0) {
     const u32 L = P.k + n - 1;
     W4 S = load_span(packed, q0 + p0, L);
     if (rev) S = w4_rc(S, L);
@@ -201,6 +202,7 @@ __device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed
     const u32 idx0p = idx_end - (n - 1) + P.suff_reduc;
     r[P.nw] = rec_header(bucket, n, idx0p);
     if (out.tag) out.tag[slot] = tag;
+    if (out.ret) out.ret[slot] = ret;
     if (out.hist) atomicAdd(&out.hist[bucket >> P.shift], 1ull | ((unsigned long long)n << 32));
 }
 
@@ -263,7 +265,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(BriskParams P, const u32* _
         const u32 idx = reversed ? w - mini_pos : mini_pos;  // Kmers.cpp:578-584
         if (closed && p > 0) {  // a close at p == 0 is ignored (Kmers.cpp:585-592)
             if (query_mode && n_emitted > 0 && ret == 0) return;
-            emit_record(P, packed, q0, p0, n, old_rev, old_rev ? first_idx : last_idx, out, (u32)r);
+            emit_record(P, packed, q0, p0, n, old_rev, old_rev ? first_idx : last_idx, out, out.ret ? p0 : (u32)r, ret);
             n_emitted++;
             n = 0;
         }
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan(BriskParams P, const u32* _
     }
     if (n > 0) {  // Kmers.cpp:596-601
         if (query_mode && n_emitted > 0 && mini == 0) return;
-        emit_record(P, packed, q0, p0, n, reversed, reversed ? first_idx : last_idx, out, (u32)r);
+        emit_record(P, packed, q0, p0, n, reversed, reversed ? first_idx : last_idx, out, out.ret ? p0 : (u32)r, mini);
     }
 }
 
@@ -841,6 +843,8 @@ struct IndexDev {
     unsigned long long* stats;   // [3] garbage entries (abandoned slices)
     unsigned long long* slot_cur;  // per persistent workgroup: private chunk [cur, end)
     unsigned long long* slot_end;
+    u32* ids;                    // entry-id mode only: stable dense id of every entry (insertion order)
+    unsigned long long arena_cap;  // entries the arena can hold (checked by k_upsert)
 };
 
 // k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
@@ -1325,7 +1329,7 @@ __global__ void __launch_bounds__(256) k_dir_counts(const DirEnt* __restrict__ d
 
 __global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u32 p_begin, u32 n_parts, const u64* __restrict__ out_base,
                                                   u64* __restrict__ out_lo, u64* __restrict__ out_hi, uint8_t* __restrict__ out_idx,
-                                                  uint8_t* __restrict__ out_cnt) {
+                                                  uint8_t* __restrict__ out_cnt, u32* __restrict__ out_id) {
     const u32 pi = blockIdx.x;
     if (pi >= n_parts) return;
     const u32 part = p_begin + pi;
@@ -1344,20 +1348,21 @@ __global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u3
         out_hi[ob + e] = hk.hi;
         out_idx[ob + e] = (uint8_t)idx;
         out_cnt[ob + e] = ix.counts[off + e];
+        if (out_id) out_id[ob + e] = ix.ids[off + e];
     }
 }
 
 // k_lookup: one wave per query (Brisk::get: hash the minimizer, find the bucket, compare compacted k-mers)
 __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, const u64* __restrict__ q_lo, const u64* __restrict__ q_hi,
                                                 const uint8_t* __restrict__ q_idx, u64 n, uint8_t* __restrict__ out_data,
-                                                uint8_t* __restrict__ out_found) {
+                                                uint8_t* __restrict__ out_found, u32* __restrict__ out_id) {
     const u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 lane = threadIdx.x & 63;
     if (qi >= n) return;
     const u32 idx = q_idx[qi];
     u128x km = mk128(q_lo[qi], q_hi[qi]);
     bool found = false;
-    u32 data = 0;
+    u32 data = 0, id = 0;
     if (idx <= P.w) {
         const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
         const u64 h = mix2m(mm, P.m_mask);
@@ -1374,6 +1379,7 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
             if (ix.keys[2 * (off + e)] == key.lo && ix.keys[2 * (off + e) + 1] == key.hi) {
                 found = true;
                 data = ix.counts[off + e];
+                if (out_id) id = ix.ids[off + e];
             }
         }
     }
@@ -1381,9 +1387,117 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
     if (bal) {
         const int src = __ffsll((long long)bal) - 1;
         data = __shfl(data, src, 64);
+        id = __shfl(id, src, 64);
     }
     if (lane == 0) {
         out_found[qi] = bal ? 1 : 0;
         out_data[qi] = (uint8_t)data;
+        if (out_id) out_id[qi] = bal ? id : 0xffffffffu;
     }
+}
+
+// ---- the per-call API of the facade (Brisk::insert_superkmer, Brisk.hpp:123-147) ----
+// entry key, partition and bucket of an UNHASHED (kmer_s, minimizer_idx): hash the minimizer
+// (Kmers.cpp:191-200), pick the bucket (Brisk.hpp:135-137), drop its nts (Kmers.cpp:138-145)
+__device__ __forceinline__ u128x key_of_kmer(const BriskParams& P, u128x km, u32 idx, u32* part, u32* bucket_out) {
+    const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
+    const u64 h = mix2m(mm, P.m_mask);
+    const u32 bucket = (u32)((h >> (2 * P.suff_reduc)) & P.bucket_mask);
+    km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
+    const u32 cut = idx + P.suff_reduc;
+    const u128x lowm = mask128(2 * cut);
+    const u128x comp = or128(andn128(shr128(km, 2 * P.b), lowm), and128(km, lowm));
+    *part = bucket >> P.shift;
+    *bucket_out = bucket;
+    return make_key(P, bucket, and128(comp, mask128(2 * P.kb)), cut);
+}
+
+// find-all then insert-missing for the k-mers of ONE vector, in order (DenseMenuYo.hpp:248-310).
+// One wave; every k-mer scans its partition with 64 lanes.  Entry-id mode: a new entry takes
+// the next dense id; DATA lives with the caller, indexed by id.  Stops (and reports how many
+// k-mers it handled) when the arena cannot hold a move; the host grows it and calls again.
+__global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const u64* __restrict__ q_lo, const u64* __restrict__ q_hi,
+                                               const uint8_t* __restrict__ q_idx, u32 n, u32* __restrict__ out_id, uint8_t* __restrict__ out_new,
+                                               unsigned long long* __restrict__ id_counter, u32* __restrict__ n_done) {
+    const u32 lane = threadIdx.x;
+    u32 done = 0;
+    for (u32 qi = 0; qi < n; qi++) {
+        const u32 idx = q_idx[qi];
+        u32 part, bucket;
+        const u128x key = key_of_kmer(P, mk128(q_lo[qi], q_hi[qi]), idx <= P.w ? idx : 0, &part, &bucket);
+        DirEnt de = ix.dir[part];
+        bool found = false;
+        u32 id = 0;
+        for (u32 e = lane; e < de.cnt && !found; e += 64) {
+            if (ix.keys[2 * (de.off + e)] == key.lo && ix.keys[2 * (de.off + e) + 1] == key.hi) {
+                found = true;
+                id = ix.ids[de.off + e];
+            }
+        }
+        const unsigned long long bal = __ballot(found);
+        if (bal) {
+            id = __shfl(id, __ffsll((long long)bal) - 1, 64);
+            if (lane == 0) {
+                out_id[qi] = id;
+                out_new[qi] = 0;
+            }
+        } else {
+            if (de.cnt == de.cap) {  // move the partition to a larger slice
+                const u32 want = grow_cap(de.cnt + 1);
+                unsigned long long noff = 0;
+                if (lane == 0) noff = atomicAdd(ix.cursor, (unsigned long long)want);
+                noff = __shfl(noff, 0, 64);
+                if (noff + want > ix.arena_cap) {  // host must grow the arena; nothing was changed for this k-mer
+                    if (lane == 0) atomicAdd(ix.cursor, (unsigned long long)(0ull - want));
+                    break;
+                }
+                for (u32 e = lane; e < de.cnt; e += 64) {
+                    ix.keys[2 * (noff + e)] = ix.keys[2 * (de.off + e)];
+                    ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (de.off + e) + 1];
+                    ix.counts[noff + e] = ix.counts[de.off + e];
+                    ix.ids[noff + e] = ix.ids[de.off + e];
+                }
+                if (lane == 0) atomicAdd(&ix.stats[3], (unsigned long long)de.cap);
+                de.off = noff;
+                de.cap = want;
+            }
+            if (lane == 0) {
+                const u32 nid = (u32)atomicAdd(id_counter, 1ull);
+                const unsigned long long at = de.off + de.cnt;
+                ix.keys[2 * at] = key.lo;
+                ix.keys[2 * at + 1] = key.hi;
+                ix.counts[at] = 0;
+                ix.ids[at] = nid;
+                ix.dir[part] = DirEnt{de.off, de.cnt + 1, de.cap};
+                atomicOr(&ix.bucket_bits[bucket >> 5], 1u << (bucket & 31));
+                out_id[qi] = nid;
+                out_new[qi] = 1;
+            }
+            __threadfence();  // the next k-mer of the vector reads this partition again
+        }
+        done = qi + 1;
+    }
+    if (lane == 0) *n_done = done;
+}
+
+// records -> the k-mers of each vector, unhashed (what SuperKmerEnumerator::next hands out):
+// one wave per record, one lane per k-mer; out row r holds up to `row` k-mers
+__global__ void __launch_bounds__(64) k_expand_records(BriskParams P, const u64* __restrict__ rec, u32 n_rec, u32 row, u64* __restrict__ out_lo,
+                                                       u64* __restrict__ out_hi, uint8_t* __restrict__ out_idx) {
+    const u32 r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_rec) return;
+    const u64* c = rec + (u64)r * P.stride;
+    const u64 hdr = c[P.nw];
+    const u32 n = hdr_n(hdr);
+    if (lane >= n) return;
+    const u32 bucket = hdr_bucket(hdr);
+    const u128x key = make_key(P, bucket, record_kmer(P, c, n, lane), hdr_idx0(hdr) + lane);
+    u32 idx;
+    u128x hk = entry_hashed_kmer(P, bucket >> P.shift, key, &idx);
+    const u64 hm = shr128(hk, 2 * idx).lo & P.m_mask;
+    const u64 mm = mix2m_inv(hm, P.m_mask);
+    hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
+    out_lo[(u64)r * row + lane] = hk.lo;
+    out_hi[(u64)r * row + lane] = hk.hi;
+    out_idx[(u64)r * row + lane] = (uint8_t)idx;
 }

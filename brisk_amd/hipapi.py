@@ -42,6 +42,30 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return out
 
 
+def build_apps(verbose: bool = False) -> dict:
+    """C++ host side: this repo's brisk_count over the facade headers, and -- where the reference
+    tree exists -- the reference's own apps/counter.cpp compiled UNCHANGED against
+    brisk_amd/include (its CLI11/zstr third-party headers are taken from the reference tree)."""
+    apps = os.path.join(HERE, "apps")
+    inc = ["-I" + os.path.join(HERE, "include"), "-I" + os.path.join(ROOT, "include")]
+    link = ["-L" + HERE, "-lbrisk_hip", "-Wl,-rpath,$ORIGIN/.."]
+    out = {}
+    cmd = ["g++", "-std=gnu++17", "-O2"] + inc + [os.path.join(apps, "brisk_count.cpp")] + link + ["-o", os.path.join(apps, "brisk_count")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    out["brisk_count"] = os.path.join(apps, "brisk_count")
+    ref_counter = "/root/reference/apps/counter.cpp"
+    if os.path.exists(ref_counter):
+        cmd = ["g++", "-std=gnu++17", "-O2", "-w", "-include", "cstdint", "-fopenmp"] + inc + ["-I/root/reference/apps", ref_counter] + link + \
+              ["-lz", "-o", os.path.join(apps, "counter_ref")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        out["counter_ref"] = os.path.join(apps, "counter_ref")
+    return out
+
+
 def coef_table(m: int) -> np.ndarray:
     """DecyclingSet(m) coefficients (reference brisk/Decycling.cpp:7-13), computed on
     the HOST with libm; the device only ever sees these bits."""
@@ -58,7 +82,7 @@ def coef_table(m: int) -> np.ndarray:
 class _Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p), ("part_bits", C.c_uint32),
                 ("owner_rank", C.c_uint32), ("n_owners", C.c_uint32), ("arena_entries", C.c_uint64),
-                ("max_batch_reads", C.c_uint64)]
+                ("max_batch_reads", C.c_uint64), ("entry_ids", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class _Layout(C.Structure):
@@ -74,7 +98,8 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_profile_enable",
+    "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
+    "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
 
@@ -110,6 +135,11 @@ def load() -> C.CDLL:
     L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
     L.brisk_hip_pack_ascii.argtypes = [vp, vp, u64, vp]
     L.brisk_hip_synth_reads.argtypes = [vp, u64, u64, u64, u32, u64, u64, vp, vp]
+    _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+    L.brisk_hip_scan_sequence.argtypes = [vp, C.c_char_p, u64, u64, _u64p, _u32p, _u64p, _u64p, _u8p, C.POINTER(u64)]
+    L.brisk_hip_upsert_kmers.argtypes = [vp, _u64p, _u64p, _u8p, u64, _u32p, _u8p]
+    L.brisk_hip_find_kmers.argtypes = [vp, _u64p, _u64p, _u8p, u64, _u32p]
+    L.brisk_hip_enumerate_ids.argtypes = [vp, C.POINTER(u64), _u64p, _u64p, _u8p, _u32p, u64, C.POINTER(u64)]
     L.brisk_hip_debug_order_keys.argtypes = [vp, _u64p, u64, i32, _u64p]
     L.brisk_hip_profile_enable.argtypes = [vp, i32]
     L.brisk_hip_profile_read.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]
@@ -134,11 +164,13 @@ class BriskHip:
     """One index handle.  Methods map one-to-one onto the C-ABI."""
 
     def __init__(self, k: int, m: int, b: int, device: int = 0, stream: Optional[int] = None, part_bits: int = 0,
-                 owner_rank: int = 0, n_owners: int = 1, arena_entries: int = 0, max_batch_reads: int = 0):
+                 owner_rank: int = 0, n_owners: int = 1, arena_entries: int = 0, max_batch_reads: int = 0,
+                 entry_ids: bool = False):
         self.L = load()
         self.h = C.c_void_p()
         self.k, self.m, self.b = k, m, b
-        opt = _Options(C.sizeof(_Options), device, stream, part_bits, owner_rank, n_owners, arena_entries, max_batch_reads)
+        opt = _Options(C.sizeof(_Options), device, stream, part_bits, owner_rank, n_owners, arena_entries, max_batch_reads,
+                       1 if entry_ids else 0, 0)
         coef = coef_table(m) if 1 <= m <= 31 else np.zeros(4, np.float64)
         rc = self.L.brisk_hip_create(C.byref(self.h), k, m, b, 1, coef.ctypes.data_as(C.POINTER(C.c_double)), C.byref(opt))
         if rc:
@@ -262,6 +294,47 @@ class BriskHip:
     def synth_reads(self, genome_len: int, first_read: int, n_reads: int, read_len: int, d_packed: int, d_starts: int,
                     seed_g: int = 1, seed_r: int = 2):
         self._chk(self.L.brisk_hip_synth_reads(self.h, genome_len, first_read, n_reads, read_len, seed_g, seed_r, d_packed, d_starts))
+
+    # ---- per-call API (entry-id mode), as the C++ facade uses it
+    def scan_sequence(self, seq):
+        s = seq.encode() if isinstance(seq, str) else bytes(seq)
+        nk = max(len(s) - self.k + 1, 1)
+        ret = np.zeros(nk, np.uint64); cnt = np.zeros(nk, np.uint32)
+        lo = np.zeros(nk, np.uint64); hi = np.zeros(nk, np.uint64); idx = np.zeros(nk, np.uint8)
+        n = C.c_uint64()
+        self._chk(self.L.brisk_hip_scan_sequence(self.h, s, len(s), nk, ret, cnt, lo, hi, idx, C.byref(n)))
+        t = int(cnt[: n.value].sum())
+        return ret[: n.value], cnt[: n.value], lo[:t], hi[:t], idx[:t]
+
+    def upsert_kmers(self, lo, hi, idx):
+        lo = np.ascontiguousarray(lo, np.uint64); hi = np.ascontiguousarray(hi, np.uint64); idx = np.ascontiguousarray(idx, np.uint8)
+        ids = np.zeros(max(len(lo), 1), np.uint32); new = np.zeros(max(len(lo), 1), np.uint8)
+        self._chk(self.L.brisk_hip_upsert_kmers(self.h, lo, hi, idx, len(lo), ids, new))
+        return ids[: len(lo)], new[: len(lo)]
+
+    def find_kmers(self, lo, hi, idx):
+        lo = np.ascontiguousarray(lo, np.uint64); hi = np.ascontiguousarray(hi, np.uint64); idx = np.ascontiguousarray(idx, np.uint8)
+        ids = np.zeros(max(len(lo), 1), np.uint32)
+        self._chk(self.L.brisk_hip_find_kmers(self.h, lo, hi, idx, len(lo), ids))
+        return ids[: len(lo)]
+
+    def enumerate_ids(self, chunk: int = 1 << 20):
+        cur = C.c_uint64(0); n = C.c_uint64(0)
+        out = [[], [], [], []]
+        cap = chunk
+        while True:
+            lo = np.zeros(cap, np.uint64); hi = np.zeros(cap, np.uint64); idx = np.zeros(cap, np.uint8); ids = np.zeros(cap, np.uint32)
+            rc = self.L.brisk_hip_enumerate_ids(self.h, C.byref(cur), lo, hi, idx, ids, cap, C.byref(n))
+            if rc == ECAPACITY:
+                cap *= 4
+                continue
+            self._chk(rc)
+            if n.value == 0:
+                break
+            for a, v in zip(out, (lo, hi, idx, ids)):
+                a.append(v[: n.value])
+        dts = (np.uint64, np.uint64, np.uint8, np.uint32)
+        return tuple(np.concatenate(a) if a else np.zeros(0, dt) for a, dt in zip(out, dts))
 
     def debug_order_keys(self, mmers, exact: bool = False) -> np.ndarray:
         x = np.ascontiguousarray(mmers, np.uint64)

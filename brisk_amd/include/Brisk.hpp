@@ -1,0 +1,183 @@
+// Brisk.hpp -- facade header with the reference's name and public surface (brisk/Brisk.hpp:23-42),
+// over the C-ABI of include/brisk_hip.h.  Everything that computes runs on the GPU; this header only
+// marshals vectors of kmer_full to flat arrays and keeps DATA (the caller's payload) in host memory,
+// addressed by the dense entry ids the device assigns.
+#ifndef BRISK_AMD_BRISK_HPP
+#define BRISK_AMD_BRISK_HPP
+#include <sys/resource.h>
+
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "DenseMenuYo.hpp"
+#include "Kmers.hpp"
+#include "buckets.hpp"
+#include "parameters.hpp"
+
+template <class DATA>
+class Brisk {
+  public:
+    DenseMenuYo<DATA>* menu;
+    Parameters params;
+
+    explicit Brisk(Parameters& parameters) : menu(nullptr), params(parameters), enum_cursor_(0), enum_pos_(0) {
+        menu = new DenseMenuYo<DATA>(params);  // throws std::invalid_argument on a bad (k, m, b)
+    }
+    ~Brisk() { delete menu; }
+    Brisk(const Brisk&) = delete;
+    Brisk& operator=(const Brisk&) = delete;
+
+    // brisk/Brisk.hpp:64-69
+    DATA* get(kmer_full& kmer) {
+        std::vector<kmer_full> one(1, kmer);
+        return find(one)[0];
+    }
+    // brisk/Brisk.hpp:123-147: entries that were absent are created; their DATA is uninitialised and
+    // newly_inserted[i] tells the caller to initialise it.  Pointers stay valid for the life of the index.
+    std::vector<DATA*> insert_superkmer(std::vector<kmer_full>& superkmer, std::vector<bool>& newly_inserted) {
+        std::vector<DATA*> result;
+        if (superkmer.empty()) return result;
+        flatten(superkmer);
+        std::lock_guard<std::mutex> g(call_mu_);
+        ids_.resize(superkmer.size());
+        new_.resize(superkmer.size());
+        check(brisk_hip_upsert_kmers(menu->handle, lo_.data(), hi_.data(), idx_.data(), superkmer.size(), ids_.data(), new_.data()));
+        for (size_t i = 0; i < superkmer.size(); i++) {
+            newly_inserted.push_back(new_[i] != 0);
+            result.push_back(slot(ids_[i]));
+        }
+        return result;
+    }
+    // brisk/Brisk.hpp:102-118: NULL for absent k-mers
+    std::vector<DATA*> get_superkmer(std::vector<kmer_full>& superkmer) { return find(superkmer); }
+    // declared by the reference (brisk/Brisk.hpp:27-28) and never defined there
+    std::vector<DATA*> insert_sequence(const std::string& str, std::vector<bool>& newly_inserted) {
+        std::vector<DATA*> all;
+        std::string s(str);
+        SuperKmerEnumerator en(s, params.k, params.m, params.dede);
+        std::vector<kmer_full> v;
+        en.next(v);
+        while (!v.empty()) {
+            std::vector<DATA*> part = insert_superkmer(v, newly_inserted);
+            all.insert(all.end(), part.begin(), part.end());
+            v.clear();
+            en.next(v);
+        }
+        return all;
+    }
+    std::vector<DATA*> get_sequence(const std::string& str) {
+        std::vector<DATA*> all;
+        std::string s(str);
+        SuperKmerEnumerator en(s, params.k, params.m, params.dede);
+        std::vector<kmer_full> v;
+        en.next(v);
+        while (!v.empty()) {
+            std::vector<DATA*> part = get_superkmer(v);
+            all.insert(all.end(), part.begin(), part.end());
+            v.clear();
+            en.next(v);
+        }
+        return all;
+    }
+    // brisk/Brisk.hpp:152-161: the reference takes a lock stripe the caller holds while it touches DATA
+    void protect_data(const kmer_full&) { data_mu_.lock(); }
+    void unprotect_data(const kmer_full&) { data_mu_.unlock(); }
+    // brisk/Brisk.hpp:166-179: every entry once, k-mer unhashed, ascending bucket range
+    bool next(kmer_full& kmer) {
+        std::lock_guard<std::mutex> g(call_mu_);
+        if (enum_pos_ >= e_lo_.size()) {
+            const uint64_t cap = 1u << 16;
+            e_lo_.resize(cap);
+            e_hi_.resize(cap);
+            e_idx_.resize(cap);
+            e_ids_.resize(cap);
+            uint64_t n = 0;
+            int rc = brisk_hip_enumerate_ids(menu->handle, &enum_cursor_, e_lo_.data(), e_hi_.data(), e_idx_.data(), e_ids_.data(), cap, &n);
+            for (uint64_t bigger = cap * 16; rc == BRISK_HIP_ECAPACITY; bigger *= 16) {  // one bucket range larger than the buffer
+                e_lo_.resize(bigger);
+                e_hi_.resize(bigger);
+                e_idx_.resize(bigger);
+                e_ids_.resize(bigger);
+                rc = brisk_hip_enumerate_ids(menu->handle, &enum_cursor_, e_lo_.data(), e_hi_.data(), e_idx_.data(), e_ids_.data(), bigger, &n);
+            }
+            check(rc);
+            e_lo_.resize(n);
+            e_hi_.resize(n);
+            enum_pos_ = 0;
+            if (n == 0) return false;
+        }
+        kmer.kmer_s = ((kint)e_hi_[enum_pos_] << 64) | e_lo_[enum_pos_];
+        kmer.minimizer_idx = e_idx_[enum_pos_];
+        kmer.compute_mini(params.m);
+        kmer.interleaved.clear();
+        enum_pos_++;
+        return true;
+    }
+    void restart_kmer_enumeration() {
+        std::lock_guard<std::mutex> g(call_mu_);
+        enum_cursor_ = 0;
+        enum_pos_ = 0;
+        e_lo_.clear();
+        e_hi_.clear();
+    }
+    // brisk/Brisk.hpp:194-197.  memory_usage is the process' peak RSS in kB, as in the reference.
+    void stats(uint64_t& nb_buckets, uint64_t& nb_skmers, uint64_t& nb_kmers, uint64_t& memory_usage, uint64_t& largest_bucket) const {
+        uint64_t dev_bytes = 0;
+        std::lock_guard<std::mutex> g(call_mu_);
+        check(brisk_hip_stats(menu->handle, &nb_buckets, &nb_skmers, &nb_kmers, &dev_bytes, &largest_bucket));
+        memory_usage = getMemorySelfMaxUsed();
+    }
+    uint64_t getMemorySelfMaxUsed() const {
+        struct rusage usage;
+        return getrusage(RUSAGE_SELF, &usage) == 0 ? (uint64_t)usage.ru_maxrss : 0;
+    }
+    // brisk/Brisk.hpp:202-224 re-buckets to (m+2, b+2); its only call site is commented out there
+    // (:124-129).  Not built: SURVEY.md 8(f)-3.
+    void reallocate() {}
+
+  private:
+    void check(int rc) const {
+        if (rc != BRISK_HIP_OK) throw std::runtime_error(std::string("brisk_hip: ") + brisk_hip_last_error(menu->handle));
+    }
+    void flatten(const std::vector<kmer_full>& v) {
+        lo_.resize(v.size());
+        hi_.resize(v.size());
+        idx_.resize(v.size());
+        for (size_t i = 0; i < v.size(); i++) {
+            lo_[i] = (uint64_t)v[i].kmer_s;
+            hi_[i] = (uint64_t)(v[i].kmer_s >> 64);
+            idx_[i] = v[i].minimizer_idx;
+        }
+    }
+    std::vector<DATA*> find(std::vector<kmer_full>& v) {
+        std::vector<DATA*> result(v.size(), nullptr);
+        if (v.empty()) return result;
+        std::lock_guard<std::mutex> g(call_mu_);
+        flatten(v);
+        ids_.resize(v.size());
+        check(brisk_hip_find_kmers(menu->handle, lo_.data(), hi_.data(), idx_.data(), v.size(), ids_.data()));
+        for (size_t i = 0; i < v.size(); i++)
+            if (ids_[i] != 0xffffffffu) result[i] = slot(ids_[i]);
+        return result;
+    }
+    // host DATA store: fixed-size chunks so that pointers never move
+    DATA* slot(uint32_t id) {
+        const size_t c = id >> 16;
+        while (chunks_.size() <= c) chunks_.emplace_back(new DATA[1u << 16]);
+        return &chunks_[c][id & 0xffff];
+    }
+    mutable std::mutex call_mu_;  // the C-ABI is thread-compatible: one call at a time per handle
+    std::mutex data_mu_;          // protect_data / unprotect_data
+    std::vector<std::unique_ptr<DATA[]>> chunks_;
+    std::vector<uint64_t> lo_, hi_, e_lo_, e_hi_;
+    std::vector<uint8_t> idx_, new_, e_idx_;
+    std::vector<uint32_t> ids_, e_ids_;
+    uint64_t enum_cursor_;
+    size_t enum_pos_;
+};
+
+#endif

@@ -39,6 +39,11 @@
  *                               apps/counter.cpp:242-261) so that records can be
  *                               exchanged between GPUs (no reference counterpart:
  *                               the reference is single-process)
+ *   brisk_hip_scan_sequence     SuperKmerEnumerator ctor + next() until empty (brisk/Kmers.cpp:509-603)
+ *   brisk_hip_upsert_kmers      Brisk::insert_superkmer (brisk/Brisk.hpp:123-147) minus the DATA pointers,
+ *                               which the facade forms from the returned ids
+ *   brisk_hip_find_kmers        Brisk::get_superkmer / Brisk::get (brisk/Brisk.hpp:64-69,102-118)
+ *   brisk_hip_enumerate_ids     Brisk::next (brisk/Brisk.hpp:166-172)
  *   brisk_hip_pack_ascii        nuc2int (brisk/Kmers.cpp:442-444) applied in bulk
  *   brisk_hip_synth_reads       no reference counterpart (benchmark input,
  *                               SURVEY.md 8(d))
@@ -78,6 +83,10 @@ typedef struct brisk_hip_options {
     uint32_t n_owners;          /* 0 or 1: this index owns every bucket */
     uint64_t arena_entries;     /* initial entry capacity of the k-mer arena; 0: grow on demand */
     uint64_t max_batch_reads;   /* reads per internal scan batch; 0: default */
+    uint32_t entry_ids;         /* 1: entry-id mode (per-call facade API): every entry gets a stable dense id in
+                                 * insertion order and DATA lives with the caller, indexed by id; bulk count
+                                 * entry points are refused on such an index */
+    uint32_t reserved0;
 } brisk_hip_options;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -153,6 +162,25 @@ int brisk_hip_route_records(brisk_hip_index *h, const uint64_t *d_records, uint6
                             uint64_t *d_out, uint64_t *counts);
 /* insert records whose buckets this index owns */
 int brisk_hip_insert_records(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records);
+
+/* ---- the per-call API under the C++ facade (entry-id mode) --------------------- */
+/* SuperKmerEnumerator over one clean sequence (len >= k): every vector next() would
+ * return, in order.  HOST arrays: skm_ret/skm_n sized >= len-k+1 vectors, km_* sized
+ * >= cap_kmers >= len-k+1 k-mers (k-mers unhashed, vector after vector). */
+int brisk_hip_scan_sequence(brisk_hip_index *h, const char *bases, uint64_t len, uint64_t cap_kmers,
+                            uint64_t *skm_ret, uint32_t *skm_n, uint64_t *km_lo, uint64_t *km_hi, uint8_t *km_idx,
+                            uint64_t *n_skm);
+/* insert_superkmer: find-all then insert-missing for the k-mers of one vector, in order.
+ * ids[i] = the entry's dense id, newly[i] = 1 if this call created it (its DATA is then
+ * uninitialised, as in the reference).  HOST arrays; n <= 255. */
+int brisk_hip_upsert_kmers(brisk_hip_index *h, const uint64_t *kmer_lo, const uint64_t *kmer_hi, const uint8_t *minimizer_idx,
+                           uint64_t n, uint32_t *ids, uint8_t *newly);
+/* get_superkmer / get: ids[i] = entry id or 0xffffffff when absent */
+int brisk_hip_find_kmers(brisk_hip_index *h, const uint64_t *kmer_lo, const uint64_t *kmer_hi, const uint8_t *minimizer_idx,
+                         uint64_t n, uint32_t *ids);
+/* next(): as brisk_hip_enumerate, returning entry ids instead of counts */
+int brisk_hip_enumerate_ids(brisk_hip_index *h, uint64_t *cursor, uint64_t *out_lo, uint64_t *out_hi,
+                            uint8_t *out_minimizer_idx, uint32_t *out_ids, uint64_t cap, uint64_t *n_out);
 
 /* ---- helpers on device buffers -------------------------------------------- */
 int brisk_hip_pack_ascii(brisk_hip_index *h, const char *d_bases, uint64_t n_bases, uint32_t *d_packed);

@@ -1,0 +1,76 @@
+"""The drop-in boundary one level up: the C++ facade with the reference's names
+(brisk_amd/include) over the C-ABI.  CPU side: it compiles -- including the reference's own
+apps/counter.cpp, UNCHANGED, where the reference tree exists.  GPU side: the built binaries
+count the reference's fixture and agree with the goldens."""
+import hashlib
+import os
+import re
+import subprocess
+
+import pytest
+
+import brisk_amd
+from conftest import GOLDEN, load_golden
+
+APPS = os.path.join(os.path.dirname(brisk_amd.__file__), "apps")
+
+
+def test_facade_compiles_and_counter_cpp_links_unchanged():
+    brisk_amd.build_library()
+    apps = brisk_amd.build_apps()
+    assert os.path.exists(apps["brisk_count"])
+    if os.path.isdir("/root/reference"):
+        assert os.path.exists(apps["counter_ref"]), "apps/counter.cpp did not compile against the facade headers"
+
+
+def test_facade_headers_carry_the_reference_surface():
+    inc = os.path.join(os.path.dirname(brisk_amd.__file__), "include")
+    brisk = open(os.path.join(inc, "Brisk.hpp")).read()
+    for name in ("insert_superkmer", "get_superkmer", "protect_data", "unprotect_data", "restart_kmer_enumeration",
+                 "insert_sequence", "get_sequence", "reallocate", "stats", "DATA* get(kmer_full& kmer)", "bool next(kmer_full& kmer)",
+                 "DenseMenuYo<DATA>* menu", "Parameters params"):
+        assert name in brisk, name
+    for f in ("Kmers.hpp", "parameters.hpp", "Decycling.h", "hashing.hpp", "buckets.hpp", "DenseMenuYo.hpp", "writer.hpp"):
+        assert os.path.exists(os.path.join(inc, f))
+
+
+def _md5_of_dump(path):
+    lines = [l for l in open(path).read().split("\n") if l]
+    return hashlib.md5("".join("{} idx={} {}\n".format(*l.split()) for l in lines).encode()).hexdigest(), lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--facade", "--bulk"])
+def test_brisk_count_binary_on_reference_fixture(tmp_path, mode):
+    exe = os.path.join(APPS, "brisk_count")
+    if not os.path.exists(exe):
+        brisk_amd.build_apps()
+    for e in load_golden("multisets.json"):
+        if e["input"] != "test.fa" or (e["k"], e["m"], e["b"]) not in ((31, 11, 4), (63, 21, 14)):
+            continue
+        dump = str(tmp_path / "dump.txt")
+        out = subprocess.run([exe, mode, os.path.join(GOLDEN, "test.fa"), str(e["k"]), str(e["m"]), str(e["b"]), dump],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.split() == ["nb_kmers", str(e["nb_kmers"]), "nb_buckets", str(e["nb_buckets"]), "sum_counts", str(e["sum_counts"])]
+        assert _md5_of_dump(dump)[0] == e["md5"]
+
+
+@pytest.mark.gpu
+def test_reference_counter_cpp_runs_on_the_gpu_index():
+    """BASELINE config #1: apps/counter on data/test.fa, k=31 m=11 b=4, with its own --mode 2 self-check.
+    The binary is the reference's counter.cpp compiled unchanged against brisk_amd/include (built where
+    the reference tree exists; it travels to the GPU box as a built artefact)."""
+    exe = os.path.join(APPS, "counter_ref")
+    if not os.path.exists(exe):
+        pytest.skip("counter_ref not built (needs the reference tree at build time)")
+    out = subprocess.run([exe, "-f", os.path.join(GOLDEN, "test.fa"), "-k", "31", "-m", "11", "-b", "4", "-t", "1", "--mode", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "All counts are correct !" in out.stdout, out.stdout[-2000:]
+    assert re.search(r"nb kmers: 6,163", out.stdout) and re.search(r"^221 bucket used", out.stdout, re.M), out.stdout[-1500:]
+    # threads: the facade serialises calls on the handle
+    out = subprocess.run([exe, "-f", os.path.join(GOLDEN, "test.fa"), "-k", "63", "-m", "21", "-b", "14", "-t", "4", "--mode", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "All counts are correct !" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    assert re.search(r"nb kmers: 6,105", out.stdout) and re.search(r"^237 bucket used", out.stdout, re.M)

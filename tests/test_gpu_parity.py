@@ -328,3 +328,32 @@ def test_long_sequences_and_ragged_lengths(B, O):
     reads += ["A" * 3000, ("ACGTTGCA" * 500)]
     for k, m, b in ((63, 21, 14), (31, 11, 11)):
         assert gpu_count(B, reads, k, m, b) == O.count(reads, k, m, b)
+
+
+def test_per_call_api_entry_ids(B, O):
+    """The facade's per-call path: scan_sequence == the enumerator stream (incl. the returned
+    minimizer values), upsert/find/enumerate_ids == insert_superkmer/get/next with DATA on the host."""
+    rng = random.Random(61)
+    reads = _random_reads(rng, 60, 900) + SPECIAL + ["".join(rng.choice("ACGT") for _ in range(700))]
+    for k, m, b in ((31, 11, 4), (63, 21, 14)):
+        with B.BriskHip(k, m, b, entry_ids=True) as ix:
+            data = {}
+            for s in reads:
+                want = O.enumerate(s.upper() if s.islower() else s, k, m)
+                got = ix.scan_sequence(s)
+                for a, c in zip(got, want[:5]):
+                    assert np.array_equal(a, c), (k, m, s[:20])
+                p = 0
+                for n in got[1]:
+                    ids, new = ix.upsert_kmers(got[2][p:p + n], got[3][p:p + n], got[4][p:p + n])
+                    for i, nw in zip(ids, new):
+                        data[int(i)] = 1 if nw else (data[int(i)] + 1) % 256  # counter.cpp:262-269
+                    assert np.array_equal(ix.find_kmers(got[2][p:p + n], got[3][p:p + n], got[4][p:p + n]), ids)
+                    p += n
+            assert sorted(data) == list(range(len(data))), "ids are dense, in insertion order"
+            lo, hi, idx, ids = ix.enumerate_ids()
+            lines = oracle.multiset_lines(lo, hi, idx, [data[int(i)] for i in ids], k)
+            st = ix.stats()
+            assert (lines, st["nb_kmers"], st["nb_buckets"]) == O.count(reads, k, m, b)
+            with pytest.raises(B.BriskHipError):
+                ix.insert_reads(reads[:2])  # bulk count is refused on an entry-id index
