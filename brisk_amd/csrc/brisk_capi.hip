@@ -25,6 +25,16 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// A device buffer that grows in place: a large virtual range is reserved once and physical
+// memory is mapped behind it on demand (HIP virtual memory management), so growing the k-mer
+// arena never copies it and never holds two generations at once.
+struct VmBuf {
+    char* base = nullptr;
+    size_t reserved = 0, mapped = 0, gran = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> sizes;
+};
+
 struct PendingEvent {
     int slot;
     hipEvent_t a, b;
@@ -48,6 +58,8 @@ struct brisk_hip_index {
     size_t scan_lds = 0;
     bool scan_v1 = false;       // BRISK_SCAN_V1=1: the plain restatement kernel
     bool entry_ids = false;
+    bool use_vmm = false;
+    VmBuf vm_keys, vm_counts, vm_ids;
     unsigned long long* d_id_counter = nullptr;
     DevBuf seq_buf;
     // the index
@@ -131,10 +143,93 @@ int launch_check(brisk_hip_index* h, const char* what) {
     return BRISK_HIP_OK;
 }
 
-// arena growth: offsets are bump-allocated, so the used prefix moves verbatim
+int vm_reserve(brisk_hip_index* h, VmBuf& b, size_t bytes) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    if (hipMemGetAllocationGranularity(&b.gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || b.gran == 0) return BRISK_HIP_EHIP;
+    const size_t step = std::max<size_t>(b.gran, (size_t)1 << 30);  // map in >= 1 GiB pieces
+    b.gran = (step + b.gran - 1) / b.gran * b.gran;
+    bytes = (bytes + b.gran - 1) / b.gran * b.gran;
+    void* p = nullptr;
+    if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) return BRISK_HIP_EHIP;
+    b.base = (char*)p;
+    b.reserved = bytes;
+    return BRISK_HIP_OK;
+}
+int vm_grow(brisk_hip_index* h, VmBuf& b, size_t bytes) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    while (b.mapped < bytes) {
+        // one physical allocation per piece of at most 8 GiB
+        size_t add = (bytes - b.mapped + b.gran - 1) / b.gran * b.gran;
+        const size_t piece_max = std::max<size_t>(b.gran, (size_t)8 << 30) / b.gran * b.gran;
+        add = std::min(add, piece_max);
+        if (b.mapped + add > b.reserved) return fail(h, BRISK_HIP_ENOMEM, "arena: virtual reservation exhausted");
+        hipMemGenericAllocationHandle_t hd;
+        hipError_t e = hipMemCreate(&hd, add, &prop, 0);
+        if (e != hipSuccess) return fail(h, BRISK_HIP_ENOMEM, std::string("arena growth: hipMemCreate: ") + hipGetErrorString(e));
+        e = hipMemMap(b.base + b.mapped, add, 0, hd, 0);
+        if (e != hipSuccess) {
+            hipMemRelease(hd);
+            return fail(h, BRISK_HIP_EHIP, std::string("arena growth: hipMemMap: ") + hipGetErrorString(e));
+        }
+        // ROCm 7.2 rejects hipMemSetAccess on some sub-ranges that start past earlier mappings
+        // ("invalid argument") but accepts the whole mapped range: always set access from the base
+        e = hipMemSetAccess(b.base, b.mapped + add, &acc, 1);
+        if (e != hipSuccess) {
+            hipMemUnmap(b.base + b.mapped, add);
+            hipMemRelease(hd);
+            return fail(h, e == hipErrorOutOfMemory ? BRISK_HIP_ENOMEM : BRISK_HIP_EHIP,
+                        std::string("arena growth: hipMemSetAccess: ") + hipGetErrorString(e) + " (mapped " + std::to_string(b.mapped >> 20) + " MiB, adding " +
+                            std::to_string(add >> 20) + " MiB)");
+        }
+        b.handles.push_back(hd);
+        b.sizes.push_back(add);
+        b.mapped += add;
+    }
+    return BRISK_HIP_OK;
+}
+void vm_free(VmBuf& b) {
+    size_t off = 0;
+    for (size_t i = 0; i < b.handles.size(); i++) {
+        hipMemUnmap(b.base + off, b.sizes[i]);
+        hipMemRelease(b.handles[i]);
+        off += b.sizes[i];
+    }
+    if (b.base) hipMemAddressFree(b.base, b.reserved);
+    b = VmBuf{};
+}
+
+// arena growth.  With virtual memory management: map more physical memory behind the reserved
+// ranges (no copy).  Without it (reservation failed at create): offsets are bump-allocated, so
+// the used prefix moves verbatim into a larger allocation.
 int ensure_arena(brisk_hip_index* h, u64 need_entries) {
     if (h->arena_used_host + need_entries <= h->arena_cap) return BRISK_HIP_OK;
-    u64 ncap = std::max<u64>(h->arena_cap * 2, h->arena_used_host + need_entries);
+    const u64 target = h->arena_used_host + need_entries;
+    if (h->use_vmm) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        u64 ncap = std::max<u64>(target, 1u << 16);
+        int rc;
+        if ((rc = vm_grow(h, h->vm_keys, ncap * 16))) return rc;
+        if ((rc = vm_grow(h, h->vm_counts, ncap))) return rc;
+        if (h->entry_ids && (rc = vm_grow(h, h->vm_ids, ncap * 4))) return rc;
+        ncap = std::min<u64>(h->vm_keys.mapped / 16, h->vm_counts.mapped);
+        if (h->entry_ids) ncap = std::min<u64>(ncap, h->vm_ids.mapped / 4);
+        h->ix.keys = (u64*)h->vm_keys.base;
+        h->ix.counts = (uint8_t*)h->vm_counts.base;
+        h->ix.ids = h->entry_ids ? (u32*)h->vm_ids.base : nullptr;
+        h->arena_cap = ncap;
+        h->ix.arena_cap = ncap;
+        return BRISK_HIP_OK;
+    }
+    u64 ncap = std::max<u64>(h->arena_cap + h->arena_cap / 4, target);
     ncap = std::max<u64>(ncap, 1u << 16);
     u64* nk = nullptr;
     uint8_t* nc = nullptr;
@@ -199,7 +294,7 @@ int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     {
         ProfScope ps(h, S_SCATTER);
         hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_cur32, (u64*)h->parted.p, 0,
-                           (const u32*)nullptr, (u32*)nullptr);
+                           (const u32*)nullptr, (u32*)nullptr, h->ix.err);
         if ((rc = launch_check(h, "k_scatter"))) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
@@ -216,7 +311,9 @@ int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->arena_used_host = h->h_small[5];
-    if ((rc = ensure_arena(h, h->h_small[3] + (u64)INSERT_SLOTS * ARENA_CHUNK))) return rc;
+    // worst case: every slice the batch may need, the tail a private chunk strands at each refill (< 1/8 of it), and
+    // one partly used chunk per persistent wave
+    if ((rc = ensure_arena(h, h->h_small[3] + h->h_small[3] / 7 + (u64)INSERT_SLOTS * ARENA_CHUNK))) return rc;
     {
         ProfScope ps(h, S_INSERT);
         HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
@@ -323,7 +420,7 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
     if ((rc = ensure(h, h->tags_b, n_rec * 4))) return rc;
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, (const u64*)h->staging.p, n_rec, h->d_cur32,
-                       (u64*)h->parted.p, 0, (const u32*)h->tags_a.p, (u32*)h->tags_b.p);
+                       (u64*)h->parted.p, 0, (const u32*)h->tags_a.p, (u32*)h->tags_b.p, h->ix.err);
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const u32 n_touched = (u32)h->h_small[2];
@@ -390,10 +487,17 @@ void free_all(brisk_hip_index* h) {
         fr(b->p);
     fr(h->d_coef);
     fr(h->d_tabs);
-    fr(h->ix.keys);
-    fr(h->ix.counts);
-    fr(h->ix.ids);
+    if (h->use_vmm) {
+        vm_free(h->vm_keys);
+        vm_free(h->vm_counts);
+        vm_free(h->vm_ids);
+    } else {
+        fr(h->ix.keys);
+        fr(h->ix.counts);
+        fr(h->ix.ids);
+    }
     fr(h->d_id_counter);
+    fr(h->ix.err);
     fr(h->seq_buf.p);
     fr(h->ix.dir);
     fr(h->ix.cursor);
@@ -509,9 +613,14 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             if (wv < 1) return fail(h, BRISK_HIP_EUNSUPPORTED, "scan state does not fit LDS");
             h->scan_waves = wv;
             h->scan_lds = fixed + wv * per_wave;
-            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
-            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
-            HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->scan_lds));
+            // the attribute is per function, not per handle: never lower it for a handle created earlier
+            static size_t lds_attr = 0;
+            if (h->scan_lds > lds_attr) {
+                lds_attr = h->scan_lds;
+                HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+                HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+                HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+            }
             const char* v1 = getenv("BRISK_SCAN_V1");
             h->scan_v1 = v1 && v1[0] == '1';
         }
@@ -535,11 +644,30 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMalloc((void**)&h->d_touched, np * 4));
         h->n_scan_blocks = nblocks(np, 256 * SCAN_ITEMS);
         HIPCHK(h, hipMalloc((void**)&h->d_block_sums, (size_t)(h->n_scan_blocks + 1) * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ix.err, 8));
+        HIPCHK(h, hipMemsetAsync(h->ix.err, 0, 8, h->stream));
         HIPCHK(h, hipMalloc((void**)&h->d_id_counter, 8));
         HIPCHK(h, hipMemsetAsync(h->d_id_counter, 0, 8, h->stream));
         HIPCHK(h, hipMalloc((void**)&h->d_small, 64));
         HIPCHK(h, hipHostMalloc((void**)&h->h_small, 64));
         HIPCHK(h, hipMemsetAsync(h->d_small, 0, 64, h->stream));
+        {
+            // reserve virtual ranges as large as the device's memory; physical pages follow demand
+            size_t free_b = 0, total_b = 0;
+            const char* novmm = getenv("BRISK_NO_VMM");
+            if (!(novmm && novmm[0] == '1') && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+                const u64 max_entries = total_b / 17;
+                if (vm_reserve(h, h->vm_keys, max_entries * 16) == BRISK_HIP_OK && vm_reserve(h, h->vm_counts, max_entries) == BRISK_HIP_OK &&
+                    (!h->entry_ids || vm_reserve(h, h->vm_ids, max_entries * 4) == BRISK_HIP_OK)) {
+                    h->use_vmm = true;
+                } else {
+                    vm_free(h->vm_keys);
+                    vm_free(h->vm_counts);
+                    vm_free(h->vm_ids);
+                    h->err.clear();
+                }
+            }
+        }
         if (o.arena_entries) {
             int rc = ensure_arena(h, o.arena_entries);
             if (rc) return rc;
@@ -574,6 +702,7 @@ BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
     HIPCHK(h, hipMemsetAsync(h->ix.dir, 0, np * sizeof(DirEnt), h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_id_counter, 0, 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ix.err, 0, 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.slot_cur, 0, INSERT_SLOTS * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.slot_end, 0, INSERT_SLOTS * 8, h->stream));
@@ -586,10 +715,19 @@ BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
 
 BRISK_API const char* brisk_hip_last_error(const brisk_hip_index* h) { return h ? h->err.c_str() : "null handle"; }
 
+static int check_device_flags(brisk_hip_index* h) {
+    u32 e = 0;
+    HIPCHK(h, hipMemcpyAsync(&e, h->ix.err, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (e) return fail(h, BRISK_HIP_EHIP, "device-side consistency check failed, flags=" + std::to_string(e) +
+                                              " (1 scatter slot out of range, 2 arena exhausted, 4 chunk overflow): the index is not valid");
+    return BRISK_HIP_OK;
+}
+
 BRISK_API int brisk_hip_sync(brisk_hip_index* h) {
     if (!h) return BRISK_HIP_EINVAL;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return BRISK_HIP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    return check_device_flags(h);
 }
 
 BRISK_API int brisk_hip_get_layout(const brisk_hip_index* h, brisk_hip_layout* out) {
@@ -733,6 +871,10 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
                               uint64_t* largest_bucket) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    {
+        int rcf = check_device_flags(h);
+        if (rcf) return rcf;
+    }
     // nb_kmers / nb_buckets / largest are reductions over the directory and the bucket bitmap
     const u64 bit_words = (h->n_buckets + 31) / 32;
     if (h->P.shift > 6) {  // partitions wider than 64 buckets: rebuild the bitmap from the entries
@@ -755,6 +897,21 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
             m += b->bytes;
         *memory_bytes = m;
     }
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_checksum(brisk_hip_index* h, uint64_t out[3]) {
+    if (!h || !out) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_small, 0, 24, h->stream));
+    hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, h->stream, h->P, h->ix, (u32)h->n_parts, h->d_small);
+    int rc;
+    if ((rc = launch_check(h, "k_checksum"))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 24, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out[0] = h->h_small[0];
+    out[1] = h->h_small[1];
+    out[2] = h->h_small[2];
     return BRISK_HIP_OK;
 }
 

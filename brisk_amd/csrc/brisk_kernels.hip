@@ -804,7 +804,8 @@ __global__ void __launch_bounds__(256) k_part_hist(BriskParams P, const u64* __r
     atomicAdd(&hist[hdr_bucket(hdr) >> P.shift], 1ull | ((unsigned long long)hdr_n(hdr) << 32));
 }
 __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u32* __restrict__ cursor,
-                                                 u64* __restrict__ out, int by_owner, const u32* __restrict__ tag_in, u32* __restrict__ tag_out) {
+                                                 u64* __restrict__ out, int by_owner, const u32* __restrict__ tag_in, u32* __restrict__ tag_out,
+                                                 u32* __restrict__ err) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     const u64* src = rec + i * P.stride;
@@ -812,6 +813,10 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
     u32 bin = hdr_bucket(hdr) >> P.shift;
     if (by_owner) bin = (u32)(((u64)bin * P.n_owners) >> P.part_bits);
     const u32 slot = atomicAdd(&cursor[bin], 1u);
+    if (slot >= n_rec) {  // histogram and records disagree: never write out of range
+        atomicOr(err, 1u);
+        return;
+    }
     u64* dst = out + (u64)slot * P.stride;
     for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
     if (tag_in) tag_out[slot] = tag_in[i];
@@ -844,7 +849,8 @@ struct IndexDev {
     unsigned long long* slot_cur;  // per persistent workgroup: private chunk [cur, end)
     unsigned long long* slot_end;
     u32* ids;                    // entry-id mode only: stable dense id of every entry (insertion order)
-    unsigned long long arena_cap;  // entries the arena can hold (checked by k_upsert)
+    unsigned long long arena_cap;  // entries the arena can hold
+    u32* err;                    // sticky violation bits: 1 scatter slot out of range, 2 arena exhausted, 4 chunk overflow
 };
 
 // k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
@@ -1125,17 +1131,29 @@ __global__ void __launch_bounds__(64) k_insert(BriskParams P, const u64* __restr
                 if (n_exist + n_new > cap) {
                     // move to a fresh slice, sized so that this partition moves at most once per batch
                     const unsigned long long want = grow_cap(n_exist + n_new + inst_left);
-                    if (acur + want > aend) {  // private chunk exhausted: abandon its tail, take a new one
-                        const unsigned long long grab = want > ARENA_CHUNK ? want : (unsigned long long)ARENA_CHUNK;
-                        garbage += aend - acur;
+                    unsigned long long noff;
+                    if (want > ARENA_CHUNK / 8) {
+                        // a large slice goes straight to the global cursor: the private chunk never strands more
+                        // than a small request (< ARENA_CHUNK/8) at a refill, which the host's reserve covers
                         unsigned long long got = 0;
-                        if (lane == 0) got = atomicAdd(ix.cursor, grab);
-                        acur = __shfl(got, 0, 64);
-                        aend = acur + grab;
+                        if (lane == 0) got = atomicAdd(ix.cursor, want);
+                        noff = __shfl(got, 0, 64);
+                    } else {
+                        if (acur + want > aend) {  // private chunk exhausted: abandon its tail, take a new one
+                            garbage += aend - acur;
+                            unsigned long long got = 0;
+                            if (lane == 0) got = atomicAdd(ix.cursor, (unsigned long long)ARENA_CHUNK);
+                            acur = __shfl(got, 0, 64);
+                            aend = acur + ARENA_CHUNK;
+                        }
+                        noff = acur;
+                        acur += want;
+                    }
+                    if (noff + want > ix.arena_cap || ninst > WI_MAX_INST) {  // must not happen (host reserves the bound): drop, flag
+                        if (lane == 0) atomicOr(ix.err, ninst > WI_MAX_INST ? 4u : 2u);
+                        break;
                     }
                     garbage += cap;
-                    const unsigned long long noff = acur;
-                    acur += want;
                     cap = (u32)want;
                     for (u32 e = lane; e < n_exist; e += 64) {
                         ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
@@ -1322,6 +1340,41 @@ __global__ void __launch_bounds__(INSERT_BLOCK) k_query(BriskParams P, const u64
 // ===========================================================================
 // k_enumerate: entries of partitions [p_begin, p_end) in order; out_base[p - p_begin]
 // is the exclusive prefix of dir_cnt over that range (Brisk::next yields unhashed k-mers).
+// order-independent digest of every entry (brisk_hip_checksum)
+__device__ __forceinline__ u64 fmix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_checksum(BriskParams P, IndexDev ix, u32 n_parts, unsigned long long* out) {
+    unsigned long long na = 0, sa = 0, da = 0;
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6, lane = threadIdx.x & 63;
+    for (u32 part = wave; part < n_parts; part += n_waves) {
+        const DirEnt de = ix.dir[part];
+        for (u32 e = lane; e < de.cnt; e += 64) {
+            const u128x key = mk128(ix.keys[2 * (de.off + e)], ix.keys[2 * (de.off + e) + 1]);
+            u32 idx;
+            u128x hk = entry_hashed_kmer(P, part, key, &idx);
+            const u64 mm = mix2m_inv(shr128(hk, 2 * idx).lo & P.m_mask, P.m_mask);
+            hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
+            const u32 cnt = ix.counts[de.off + e];
+            na += 1;
+            sa += cnt;
+            da += fmix(hk.lo ^ fmix(hk.hi ^ fmix(((u64)idx << 8) | cnt)));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        na += __shfl_xor(na, o, 64);
+        sa += __shfl_xor(sa, o, 64);
+        da += __shfl_xor(da, o, 64);
+    }
+    if (lane == 0 && na) {
+        atomicAdd(&out[0], na);
+        atomicAdd(&out[1], sa);
+        atomicAdd(&out[2], da);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_dir_counts(const DirEnt* __restrict__ dir, u64 n, u32* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = dir[i].cnt;

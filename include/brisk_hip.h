@@ -32,6 +32,8 @@
  *                               (brisk/Brisk.hpp:166-179, brisk/DenseMenuYo.hpp:476-521)
  *   brisk_hip_stats             Brisk::stats (brisk/Brisk.hpp:194-197,
  *                               brisk/DenseMenuYo.hpp:545-568)
+ *   brisk_hip_checksum          the next()+get() walk of verif_counts (apps/counter.cpp:90-126), reduced
+ *                               to a digest on the device
  *   brisk_hip_scan_packed / brisk_hip_route_records / brisk_hip_insert_records
  *                               the same insert path cut at the super-k-mer
  *                               boundary (the vector<kmer_full> handed from
@@ -147,6 +149,13 @@ int brisk_hip_enumerate(brisk_hip_index *h, uint64_t *cursor, uint64_t *out_lo, 
  * here as: super-k-mer records received, largest partition (entries). */
 int brisk_hip_stats(brisk_hip_index *h, uint64_t *nb_buckets, uint64_t *nb_skmers, uint64_t *nb_kmers,
                     uint64_t *memory_bytes, uint64_t *largest_bucket);
+
+/* Order-independent digest of the whole index, for parity checks at sizes where the multiset
+ * cannot be compared line by line: out[0] = number of entries, out[1] = sum of counts,
+ * out[2] = sum over entries of mix(kmer_lo, kmer_hi, minimizer_idx, count) mod 2^64 with
+ * mix(a,b,c,d) = f(a ^ f(b ^ f(c << 8 | d))), f = the splitmix64 finaliser (k-mers unhashed,
+ * as Brisk::next yields them).  Digests of bucket-range shards add up to the whole index's. */
+int brisk_hip_checksum(brisk_hip_index *h, uint64_t out[3]);
 
 /* ---- the path cut at the super-k-mer boundary (multi-GPU) ----------------- */
 /* scan: d_records receives up to cap_records records of record_words u64 each;

@@ -72,6 +72,21 @@ def multiset_lines(lo, hi, idx, cnt, k: int) -> List[str]:
     return sorted(f"{kmer2str(l, h, k)} {int(i)} {int(c)}" for l, h, i, c in zip(lo, hi, idx, cnt))
 
 
+def _fmix(z: int) -> int:
+    M = (1 << 64) - 1
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def digest(lo, hi, idx, cnt) -> tuple:
+    """The order-independent digest brisk_hip_checksum defines (include/brisk_hip.h)."""
+    d = 0
+    for a, b, c, e in zip(lo, hi, idx, cnt):
+        d = (d + _fmix(int(a) ^ _fmix(int(b) ^ _fmix((int(c) << 8) | int(e))))) & ((1 << 64) - 1)
+    return len(lo), int(sum(int(x) for x in cnt)), d
+
+
 def fasta_sequences(text: str) -> List[str]:
     """The harness's record/segment rules (counter.cpp:130-190):
     a record is every line up to the next '>'; it is cut at the first character

@@ -357,3 +357,55 @@ def test_per_call_api_entry_ids(B, O):
             assert (lines, st["nb_kmers"], st["nb_buckets"]) == O.count(reads, k, m, b)
             with pytest.raises(B.BriskHipError):
                 ix.insert_reads(reads[:2])  # bulk count is refused on an entry-id index
+
+
+def test_checksum_matches_oracle_digest(B, O):
+    rng = random.Random(8)
+    reads = _random_reads(rng, 700, 5000) + SPECIAL
+    for k, m, b in ((63, 21, 14), (31, 11, 4)):
+        flat, offs = oracle.pack_reads(reads)
+        h = O.index_new(k, m, b)
+        O.index_insert_reads(h, flat, offs)
+        want = oracle.digest(*O.index_dump(h))
+        O.index_free(h)
+        with B.BriskHip(k, m, b) as ix:
+            ix.insert_reads(reads)
+            assert ix.checksum() == want
+
+
+def test_full_size_properties_config2_and_3(B):
+    """BASELINE configs #2' (10M reads, k31 m11 b11: b=14 of config #2 is invalid in the reference, F1)
+    and #3 (50M reads, k63 m21 b14) at full size, through size-independent properties: the result does not
+    depend on batching or read order; every k-mer instance is counted exactly once (sum of counts ==
+    reads x (L-k+1), no count wraps at 15x coverage); counting the same reads again changes no entry and
+    doubles every count; every read's own k-mers are found."""
+    import torch
+    L = 150
+    for (n_reads, k, m, b) in ((10_000_000, 31, 11, 11), (50_000_000, 63, 21, 14)):
+        G = n_reads * L // 15
+        d_packed = torch.zeros((n_reads * L + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+        d_starts = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        with B.BriskHip(k, m, b) as ix:
+            ix.synth_reads(G, 0, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())
+            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
+            st = ix.stats()
+            one = ix.checksum()
+            assert one[0] == st["nb_kmers"]
+            assert one[1] == n_reads * (L - k + 1)
+            # same reads again: no new entry, every count doubled
+            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
+            two = ix.checksum()
+            assert two[0] == one[0] and two[1] == 2 * one[1] and ix.stats()["nb_buckets"] == st["nb_buckets"]
+        # five batches, last batch first: identical index
+        with B.BriskHip(k, m, b) as ix:
+            step = n_reads // 5
+            for i in reversed(range(5)):
+                sl = d_starts[i * step:(i + 1) * step + 1].contiguous()
+                torch.cuda.synchronize()
+                ix.insert_packed(d_packed.data_ptr(), sl.data_ptr(), step)
+            assert ix.checksum() == one
+            st2 = ix.stats()
+            assert (st2["nb_kmers"], st2["nb_buckets"]) == (st["nb_kmers"], st["nb_buckets"])
+        del d_packed, d_starts
+        torch.cuda.empty_cache()
