@@ -163,7 +163,7 @@ def main():
             bytes_per_launch = b_alg(k, m, b, L, n_skm) * reads_per_launch
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, k, m, b, n_reads),
                         "avg_launch_ms": round(avg_ms, 3), "alg_bytes_per_read": b_alg(k, m, b, L, n_skm),
                         "kernels_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in prof.items() if v["launches"]}}
         cpu = None
@@ -184,6 +184,26 @@ def main():
         print(json.dumps(line))
     if N > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, k, m, b, n_reads):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes, KiB, uncorrected --
+    on gfx950 FETCH_SIZE under-reports reads).  None when the committed passes
+    were taken on another workload: PMC counters cannot be collected from inside this process."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    w = d.get("workload", {})
+    if (w.get("k"), w.get("m"), w.get("b"), w.get("reads")) != (k, m, b, n_reads):
+        return None
+    name = {"k_scan": "k_scan2<5>"}.get(kernel, kernel)
+    e = d.get("kernels", {}).get(name)
+    if not e or not e.get("launches"):
+        return None
+    return round((e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024 / e["launches"])
 
 
 def cpu_baseline(k, m, b, L, coverage, sample_reads):
