@@ -818,7 +818,15 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
         return;
     }
     u64* dst = out + (u64)slot * P.stride;
-    for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
+    if (P.stride == 4) {  // 32-byte records (k63/m21/b14): two 16-byte moves
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        const uint4 a = s4[0], b = s4[1];
+        d4[0] = a;
+        d4[1] = b;
+    } else {
+        for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
+    }
     if (tag_in) tag_out[slot] = tag_in[i];
 }
 
@@ -899,10 +907,11 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 x, u32 lane) {
 
 // k-mer j of record words in LDS, branch-free (every load is unconditional so that the
 // unrolled instances of a lane keep their LDS reads in flight together)
+template <u32 NW>  // NW > 0: compile-time record width; 0: P.nw
 __device__ __forceinline__ u128x record_kmer_lds(const BriskParams& P, const u64* c, u32 n, u32 j) {
     const u32 s = 2 * (n - 1 - j);
     const u32 ws = s >> 6, bs = s & 63;
-    const u32 last = P.nw - 1;
+    const u32 last = (NW ? NW : P.nw) - 1;
     const u64 t0 = c[ws < last ? ws : last], t1 = c[ws + 1 < last ? ws + 1 : last], t2 = c[ws + 2 < last ? ws + 2 : last];
     const u64 a0 = ws <= last ? t0 : 0, a1 = ws + 1 <= last ? t1 : 0, a2 = ws + 2 <= last ? t2 : 0;
     u128x r;
@@ -915,7 +924,7 @@ __device__ __forceinline__ u128x record_kmer_lds(const BriskParams& P, const u64
 
 // WI_NI-instances-per-lane body of the expand + de-duplicate phases (NI = 4 when the
 // chunk has <= 256 instances, else 8: all NI instances of a lane are in flight together)
-template <u32 NI>
+template <u32 NI, u32 NW>
 __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane, u32 ninst, u32 tsize, const u64* s_rec, const u32* s_pref,
                                                   const uint8_t* s_irec, const u32* s_rmult, u64* s_key, u32* s_tab) {
     u64 klo[NI], khi[NI];
@@ -930,10 +939,10 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
     for (u32 it = 0; it < NI; it++) {
         const u32 i = it * 64 + lane;
         const u32 r = rix[it];
-        const u64* c = s_rec + r * P.stride;
-        const u64 hdr = c[P.nw];
+        const u64* c = s_rec + r * (NW ? NW + 1 : P.stride);
+        const u64 hdr = c[NW ? NW : P.nw];
         const u32 j = i < ninst ? i - s_pref[r] : 0;
-        const u128x key = make_key(P, hdr_bucket(hdr), record_kmer_lds(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+        const u128x key = make_key(P, hdr_bucket(hdr), record_kmer_lds<NW>(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
         klo[it] = key.lo;
         khi[it] = key.hi;
         hh[it] = hash_key32(key) & (tsize - 1);
@@ -1089,10 +1098,15 @@ __global__ void __launch_bounds__(64) k_insert(BriskParams P, const u64* __restr
                 if (rc == d.r_begin && tn < t_end) rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
 
                 // ---- 0/1. expand to entry keys and de-duplicate
-                if (ninst <= 256)
-                    expand_and_dedupe<4>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                else
-                    expand_and_dedupe<WI_NI>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                if (P.nw == 3) {  // k63/m21/b14 and neighbours: compile-time record width
+                    if (ninst <= 128) expand_and_dedupe<2, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (ninst <= 256) expand_and_dedupe<4, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else expand_and_dedupe<WI_NI, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                } else {
+                    if (ninst <= 128) expand_and_dedupe<2, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (ninst <= 256) expand_and_dedupe<4, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else expand_and_dedupe<WI_NI, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                }
                 wave_sync();
 
                 // ---- 2. existing entries probe the table
