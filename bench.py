@@ -51,7 +51,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
-    ap.add_argument("--verify", action="store_true", help="after timing, check a property of the result")
     args = ap.parse_args()
 
     import numpy as np
@@ -141,12 +140,18 @@ def main():
     dt = float(t.item())
     entries_all = float(e.item())
 
-    verify = None
-    if args.verify:
-        # size-independent property: every read's own k-mers are present, so a bulk query of
-        # a sample of the inserted reads returns at least (L-k+1) per read, and the index is idempotent
-        one_job(False)
-        verify = {"nb_kmers": ix.stats()["nb_kmers"]}
+    # after the timed region: a size-independent parity property of what was just built -- every k-mer
+    # instance counted exactly once (sum of counts == reads x (L-k+1); no count wraps at this coverage) and
+    # an order-independent digest of the index (shard digests add up; equal digests <=> equal multisets)
+    ent, sumc, dig = ix.checksum()
+    limbs = [(dig >> (22 * i)) & ((1 << 22) - 1) for i in range(3)]  # int64 all-reduce cannot overflow on 22-bit limbs
+    chk = torch.tensor([ent, sumc] + limbs, dtype=torch.int64, device=dev)
+    if N > 1:
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    chk = [int(v) for v in chk.cpu().tolist()]
+    verify = {"entries": chk[0], "sum_counts": chk[1], "sum_counts_expected": total_reads * max(L - k + 1, 0),
+              "every_kmer_counted_once": chk[1] == total_reads * max(L - k + 1, 0),
+              "digest_mod_2_64": (chk[2] + (chk[3] << 22) + (chk[4] << 44)) % (1 << 64)}
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -179,8 +184,7 @@ def main():
                        "parallelism": "bucket-range shard x%d + all-to-all" % N if N > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if verify:
-            line["verify"] = verify
+        line["verify"] = verify
         print(json.dumps(line))
     if N > 1:
         dist.destroy_process_group()
