@@ -1,10 +1,11 @@
 // brisk_count -- this repo's own small k-mer counter over the facade / C-ABI (not the reference's
 // apps/counter.cpp, which compiles unchanged against brisk_amd/include and is built by the tests).
 //   brisk_count --facade FASTA k m b [dump.txt]   per-call API: SuperKmerEnumerator + Brisk<uint8_t>
-//   brisk_count --bulk   FASTA k m b [dump.txt]   bulk C-ABI: brisk_hip_insert_reads
+//   brisk_count --bulk   FASTA k m b [dump.txt]   bulk C-ABI: brisk_hip_insert_reads, FASTA or FASTA.gz streamed in batches
 // Prints nb_kmers / nb_buckets / sum of counts; optionally dumps "KMER idx count" lines.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -12,36 +13,17 @@
 #include <vector>
 
 #include "Brisk.hpp"
+#include "brisk_fasta.hpp"
 
-// a FASTA record is every line up to the next '>'; it is cut at each character outside
-// [ACGTacgt], the pieces are separate sequences, upper-cased (the rules of counter.cpp:130-190)
 static std::vector<std::string> read_fasta(const char* path) {
-    std::ifstream in(path);
-    if (!in) {
-        std::cerr << "cannot open " << path << std::endl;
-        exit(1);
-    }
     std::vector<std::string> out;
-    std::string line, cur;
-    auto flush = [&]() {
-        std::string piece;
-        for (char c : cur) {
-            const char u = (char)toupper((unsigned char)c);
-            if (u == 'A' || u == 'C' || u == 'G' || u == 'T') {
-                piece += u;
-            } else if (!piece.empty()) {
-                out.push_back(piece);
-                piece.clear();
-            }
-        }
-        if (!piece.empty()) out.push_back(piece);
-        cur.clear();
-    };
-    while (std::getline(in, line)) {
-        if (!line.empty() && line[0] == '>') flush();
-        else cur += line;
+    FastaReader rd(path);
+    FastaBatch b;
+    b.clear();
+    while (rd.fill(b, (size_t)1 << 26)) {
+        if (rd.done()) break;
     }
-    flush();
+    for (size_t i = 0; i < b.size(); i++) out.push_back(b.flat.substr(b.offs[i], b.offs[i + 1] - b.offs[i]));
     return out;
 }
 
@@ -51,7 +33,8 @@ int main(int argc, char** argv) {
         return 2;
     }
     const bool bulk = !strcmp(argv[1], "--bulk");
-    const std::vector<std::string> seqs = read_fasta(argv[2]);
+    const size_t batch_bases = getenv("BRISK_BATCH_BASES") ? (size_t)atoll(getenv("BRISK_BATCH_BASES")) : ((size_t)256 << 20);
+    const std::vector<std::string> seqs = bulk ? std::vector<std::string>() : read_fasta(argv[2]);
     const uint8_t k = (uint8_t)atoi(argv[3]), m = (uint8_t)atoi(argv[4]), b = (uint8_t)atoi(argv[5]);
     const char* dump = argc > 6 ? argv[6] : nullptr;
     Parameters params(k, m, b);
@@ -100,16 +83,15 @@ int main(int argc, char** argv) {
                 std::cerr << "brisk_hip_create failed: " << rc << std::endl;
                 return 1;
             }
-            std::string flat;
-            std::vector<uint64_t> offs(1, 0);
-            for (const std::string& s : seqs) {
-                flat += s;
-                offs.push_back(flat.size());
-            }
-            rc = brisk_hip_insert_reads(h, flat.data(), offs.data(), seqs.size());
-            if (rc != BRISK_HIP_OK) {
-                std::cerr << brisk_hip_last_error(h) << std::endl;
-                return 1;
+            // stream the file: a background thread inflates and segments batch i+1 while the GPU counts batch i
+            FastaBatcher batches(argv[2], batch_bases);
+            FastaBatch bt;
+            while (batches.next(bt)) {
+                rc = brisk_hip_insert_reads(h, bt.flat.data(), bt.offs.data(), bt.size());
+                if (rc != BRISK_HIP_OK) {
+                    std::cerr << brisk_hip_last_error(h) << std::endl;
+                    return 1;
+                }
             }
             brisk_hip_stats(h, &nb_buckets, &nb_skmers, &nb_kmers, &mem, &largest);
             uint64_t cursor = 0, n = 0;

@@ -50,7 +50,7 @@ def build_apps(verbose: bool = False) -> dict:
     inc = ["-I" + os.path.join(HERE, "include"), "-I" + os.path.join(ROOT, "include")]
     link = ["-L" + HERE, "-lbrisk_hip", "-Wl,-rpath,$ORIGIN/.."]
     out = {}
-    cmd = ["g++", "-std=gnu++17", "-O2"] + inc + [os.path.join(apps, "brisk_count.cpp")] + link + ["-o", os.path.join(apps, "brisk_count")]
+    cmd = ["g++", "-std=gnu++17", "-O2", "-pthread"] + inc + [os.path.join(apps, "brisk_count.cpp")] + link + ["-lz", "-o", os.path.join(apps, "brisk_count")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

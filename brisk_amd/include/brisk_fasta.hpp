@@ -1,0 +1,169 @@
+// brisk_fasta.hpp -- host FASTA / FASTA.gz front-end for the bulk path.
+// Same record and segment rules as the reference's harness (apps/counter.cpp:130-190):
+//   * a record is its first line (the header, whatever it holds) plus every following line up
+//     to the next line that starts with '>', concatenated;
+//   * the record is cut at every character outside [ACGTacgt]; each maximal run of valid bases
+//     is a sequence of its own; sequences are upper-cased.
+// Input is inflated with zlib (gzread reads plain files transparently, as zstr does for the
+// reference).  FastaBatcher parses on a background thread while the GPU counts the previous
+// batch (the reference serialises parsing in one omp critical section, counter.cpp:217-220).
+#ifndef BRISK_AMD_FASTA_HPP
+#define BRISK_AMD_FASTA_HPP
+#include <zlib.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct FastaBatch {
+    std::string flat;            // concatenated sequences
+    std::vector<uint64_t> offs;  // offs[n+1]
+    size_t size() const { return offs.empty() ? 0 : offs.size() - 1; }
+    void clear() {
+        flat.clear();
+        offs.assign(1, 0);
+    }
+};
+
+class FastaReader {
+  public:
+    explicit FastaReader(const std::string& path) : gz_(gzopen(path.c_str(), "rb")), pos_(0), len_(0), eof_(false), in_header_(true), at_line_start_(true) {
+        if (!gz_) throw std::runtime_error("cannot open " + path);
+        gzbuffer(gz_, 1 << 20);
+        buf_.resize(8 << 20);  // zstr's buffer size (zstr.hpp:222)
+    }
+    ~FastaReader() {
+        if (gz_) gzclose(gz_);
+    }
+    FastaReader(const FastaReader&) = delete;
+    FastaReader& operator=(const FastaReader&) = delete;
+
+    // Appends sequences to `out` until it holds at least max_bases bases or the file ends.
+    // Returns false when nothing was appended and the file is exhausted.
+    bool fill(FastaBatch& out, size_t max_bases) {
+        if (out.offs.empty()) out.offs.assign(1, 0);
+        const size_t before = out.size();
+        while (out.flat.size() < max_bases) {
+            if (pos_ == len_ && !refill()) break;
+            const char c = buf_[pos_++];
+            if (at_line_start_) {
+                at_line_start_ = false;
+                if (c == '>' && !in_header_) {  // next record: close the running sequence
+                    close_run(out);
+                    in_header_ = true;
+                }
+            }
+            if (c == '\n') {
+                at_line_start_ = true;
+                in_header_ = false;  // the first line of a record is its header
+                continue;
+            }
+            if (in_header_) continue;
+            const char u = (char)(c & ~0x20);
+            if (u == 'A' || u == 'C' || u == 'G' || u == 'T') {
+                out.flat.push_back(u);
+            } else {
+                close_run(out);
+            }
+        }
+        if (eof_ && pos_ == len_) close_run(out);
+        return out.size() > before || !(eof_ && pos_ == len_);
+    }
+    bool done() const { return eof_ && pos_ == len_; }
+
+  private:
+    void close_run(FastaBatch& out) {
+        if (out.flat.size() > out.offs.back()) out.offs.push_back(out.flat.size());
+    }
+    bool refill() {
+        if (eof_) return false;
+        const int n = gzread(gz_, &buf_[0], (unsigned)buf_.size());
+        if (n < 0) throw std::runtime_error("gzread failed");
+        pos_ = 0;
+        len_ = (size_t)n;
+        if (n == 0) eof_ = true;
+        return n > 0;
+    }
+    gzFile gz_;
+    std::string buf_;
+    size_t pos_, len_;
+    bool eof_, in_header_, at_line_start_;
+};
+
+// Double-buffered batches: a background thread parses batch i+1 while the caller consumes batch i.
+class FastaBatcher {
+  public:
+    FastaBatcher(const std::string& path, size_t batch_bases) : reader_(path), batch_bases_(batch_bases), ready_(false), finished_(false), stop_(false) {
+        worker_ = std::thread([this] { run(); });
+    }
+    ~FastaBatcher() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (worker_.joinable()) worker_.join();
+    }
+    // Moves the next batch into `out`; false when the file is exhausted.
+    bool next(FastaBatch& out) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return ready_ || finished_; });
+        if (!ready_) {
+            if (!error_.empty()) throw std::runtime_error(error_);
+            return false;
+        }
+        std::swap(out, slot_);
+        ready_ = false;
+        lk.unlock();
+        cv_.notify_all();
+        return true;
+    }
+
+  private:
+    void run() {
+        try {
+            for (;;) {
+                FastaBatch b;
+                b.clear();
+                // a batch may end inside a sequence only at the end of the file: keep reading until a run closes
+                bool more = reader_.fill(b, batch_bases_);
+                while (more && !reader_.done() && b.flat.size() > b.offs.back()) more = reader_.fill(b, b.flat.size() + (1 << 16));
+                if (b.flat.size() > b.offs.back()) b.offs.push_back(b.flat.size());
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return !ready_ || stop_; });
+                if (stop_) return;
+                if (b.size() > 0) {
+                    std::swap(slot_, b);
+                    ready_ = true;
+                }
+                if (reader_.done()) {
+                    finished_ = true;
+                    lk.unlock();
+                    cv_.notify_all();
+                    return;
+                }
+                lk.unlock();
+                cv_.notify_all();
+            }
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> g(mu_);
+            error_ = e.what();
+            finished_ = true;
+            cv_.notify_all();
+        }
+    }
+    FastaReader reader_;
+    size_t batch_bases_;
+    FastaBatch slot_;
+    bool ready_, finished_, stop_;
+    std::string error_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::thread worker_;
+};
+
+#endif

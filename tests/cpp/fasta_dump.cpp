@@ -1,0 +1,13 @@
+// prints every sequence the host front-end yields for a FASTA / FASTA.gz file, one per line
+#include <iostream>
+
+#include "brisk_fasta.hpp"
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    FastaBatcher batches(argv[1], (size_t)atoll(argv[2]));
+    FastaBatch b;
+    while (batches.next(b))
+        for (size_t i = 0; i < b.size(); i++) std::cout << b.flat.substr(b.offs[i], b.offs[i + 1] - b.offs[i]) << "\n";
+    return 0;
+}

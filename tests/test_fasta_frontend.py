@@ -1,0 +1,63 @@
+"""Host FASTA / FASTA.gz front-end (brisk_amd/include/brisk_fasta.hpp) against the
+segmentation rules of the reference's harness (apps/counter.cpp:130-190), restated in
+oracle.fasta_sequences.  CPU only."""
+import gzip
+import os
+import random
+import subprocess
+
+import pytest
+
+import brisk_amd
+import oracle
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def dumper(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bin") / "fasta_dump")
+    subprocess.check_call(["g++", "-std=gnu++17", "-O2", "-pthread", "-I" + os.path.join(os.path.dirname(brisk_amd.__file__), "include"),
+                           os.path.join(ROOT, "tests", "cpp", "fasta_dump.cpp"), "-lz", "-o", exe])
+    return exe
+
+
+def run(dumper, path, batch):
+    out = subprocess.run([dumper, path, str(batch)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return [l for l in out.stdout.split("\n") if l]
+
+
+def test_reference_fixtures_plain_and_gz(dumper, tmp_path):
+    for name in ("test.fa", "debug_test.fa"):
+        text = open(os.path.join(GOLDEN, name)).read()
+        want = oracle.fasta_sequences(text)
+        assert run(dumper, os.path.join(GOLDEN, name), 1 << 20) == want
+        gz = str(tmp_path / (name + ".gz"))
+        with gzip.open(gz, "wt") as f:
+            f.write(text)
+        for batch in (1 << 20, 1000, 1):  # tiny batches: a batch never ends inside a sequence
+            assert run(dumper, gz, batch) == want
+
+
+def test_ragged_input(dumper, tmp_path):
+    rng = random.Random(4)
+    recs = []
+    for i in range(200):
+        body = "".join(rng.choice("ACGTacgtNnRY-") if rng.random() < 0.1 else rng.choice("ACGT") for _ in range(rng.randint(0, 400)))
+        lines = [body[j:j + 60] for j in range(0, len(body), 60)]
+        if rng.random() < 0.2:
+            lines.insert(rng.randint(0, len(lines)), "")
+        recs.append(">r%d some description\n" % i + "\n".join(lines))
+    text = "\n".join(recs)  # no trailing newline
+    p = str(tmp_path / "ragged.fa")
+    open(p, "w").write(text)
+    want = oracle.fasta_sequences(text)
+    assert want and run(dumper, p, 4096) == want
+    # CRLF line ends: '\r' is not a base, so it cuts sequences exactly as it does in the reference's reader
+    p2 = str(tmp_path / "crlf.fa")
+    open(p2, "w", newline="").write(">x\r\nACGT\r\nACGT\r\n>y\r\nTTTT")
+    assert run(dumper, p2, 100) == ["ACGT", "ACGT", "TTTT"]
+    # the first line of a file is a header whatever it holds (getLineFasta, counter.cpp:173-178)
+    p3 = str(tmp_path / "nohdr.fa")
+    open(p3, "w").write("ACGTACGT\nGGGG\n>z\nCCCC\n")
+    assert run(dumper, p3, 100) == ["GGGG", "CCCC"]

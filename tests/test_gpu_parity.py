@@ -409,3 +409,27 @@ def test_full_size_properties_config2_and_3(B):
             assert (st2["nb_kmers"], st2["nb_buckets"]) == (st["nb_kmers"], st["nb_buckets"])
         del d_packed, d_starts
         torch.cuda.empty_cache()
+
+
+def test_mixed_insert_get_workload(B, O):
+    """BASELINE config #5's shape (no real FASTA stream exists offline: Accessions_List holds IDs only):
+    batches of reads are inserted and queried alternately; after every batch the bulk query of the batch
+    just inserted and of the NEXT batch (mostly absent k-mers) equals the CPU path's, and so does the final state."""
+    rng = random.Random(55)
+    reads = _random_reads(rng, 3000, 20000) + SPECIAL
+    rng.shuffle(reads)
+    k, m, b = 63, 21, 14
+    h = O.index_new(k, m, b)
+    step = 400
+    with B.BriskHip(k, m, b) as ix:
+        for i in range(0, len(reads), step):
+            cur, nxt = reads[i:i + step], reads[i + step:i + 2 * step]
+            f, o = oracle.pack_reads(cur)
+            O.index_insert_reads(h, f, o)
+            ix.insert_reads(cur)
+            assert np.array_equal(ix.get_reads(cur), O.index_query_reads(h, f, o))
+            if nxt:
+                f2, o2 = oracle.pack_reads(nxt)
+                assert np.array_equal(ix.get_reads(nxt), O.index_query_reads(h, f2, o2))
+        assert ix.checksum() == oracle.digest(*O.index_dump(h))
+    O.index_free(h)
