@@ -1,10 +1,13 @@
 """ctypes binding of include/brisk_hip.h (one-to-one; no logic)."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import math
 import os
 import subprocess
+import sys
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -161,6 +164,20 @@ def _pack_reads(seqs) -> Tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(flat), offs
 
 
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all_handles():
+    # destroy device state while the HIP runtime is still up: finalisers that run during
+    # interpreter teardown would call into a runtime that may already be gone
+    for ix in list(_live):
+        try:
+            ix.close()
+        except Exception:
+            pass
+
+
 class BriskHip:
     """One index handle.  Methods map one-to-one onto the C-ABI."""
 
@@ -177,6 +194,7 @@ class BriskHip:
         if rc:
             self.h = C.c_void_p()
             raise BriskHipError(rc, f"create(k={k},m={m},b={b})")
+        _live.add(self)
         lay = _Layout()
         self._chk(self.L.brisk_hip_get_layout(self.h, C.byref(lay)))
         self.layout = {n: getattr(lay, n) for n, _ in _Layout._fields_}
@@ -192,6 +210,8 @@ class BriskHip:
             self.h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
