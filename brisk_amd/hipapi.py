@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-_LIB_NAME = "libbrisk_hip.so"
+_LIB_NAME = os.environ.get("BRISK_HIP_LIB", "libbrisk_hip.so")
 
 STATUS = {0: "OK", 1: "EINVAL", 2: "EUNSUPPORTED", 3: "EHIP", 4: "ENOMEM", 5: "ECAPACITY", 6: "ENODEVICE"}
 ECAPACITY = 5
