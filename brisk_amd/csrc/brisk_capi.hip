@@ -550,7 +550,6 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     P.kb = k - b;
     P.nw = (2 * (2 * k - m - b) + 63) / 64;
     P.stride = P.nw + 1;
-    P.key_comp_sh = 6;
     P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(2u * b, 24u);
     P.shift = 2 * b - P.part_bits;
     // the entry key [bucket low bits | compacted | idx'] must fit 128 bits

@@ -21,7 +21,6 @@ struct BriskParams {
     u32 stride;      // nw + 1: record words, last one is the header
     u32 part_bits;   // log2(#partitions)
     u32 shift;       // 2b - part_bits: bucket bits kept inside an entry key
-    u32 key_comp_sh; // 6: compacted k-mer sits above the 6-bit idx'
     u32 n_owners, owner_rank;
     u64 m_mask;      // 2m ones
     u64 bucket_mask; // 2b ones
