@@ -425,10 +425,16 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const u32 n_touched = (u32)h->h_small[2];
     if (n_touched == 0) return BRISK_HIP_OK;
+    if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched, h->ix.dir,
+                       (PartDesc*)h->desc.p, h->d_small + 3);
     {
         ProfScope ps(h, S_QUERY);
-        hipLaunchKernelGGL(k_query, dim3(std::min<u32>(n_touched, 4096u)), dim3(INSERT_BLOCK), 0, h->stream, P, (const u64*)h->parted.p,
-                           (const u32*)h->tags_b.p, h->d_off, h->d_touched, n_touched, h->ix, d_sums);
+        HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
+        hipLaunchKernelGGL(k_query, dim3(std::min<u32>((n_touched + WI_BATCH - 1) / WI_BATCH, INSERT_SLOTS)), dim3(64), 0, h->stream, P,
+                           (const u64*)h->parted.p, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums,
+                           (u32*)(h->d_small + 6));
     }
     return launch_check(h, "k_query");
 }

@@ -12,10 +12,6 @@
 #include "brisk_device.h"
 
 #define SCAN_BLOCK 256
-#define INSERT_BLOCK 256
-#define INS_TABLE 2048      // LDS hash slots per partition chunk
-#define INS_MAX_INST 1280   // k-mer instances per chunk (load <= 0.625)
-#define INS_MAX_REC 128     // records per chunk
 #define EMPTY_SLOT 0xffffffffu
 #define MATCHED_BIT 0x80000000u
 
@@ -832,7 +828,7 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
 
 // ===========================================================================
 // k_insert: persistent workgroups, each walking a strided share of the touched
-// partitions.  Per partition (per chunk of at most INS_MAX_INST k-mer instances):
+// partitions.  Per partition (per chunk of at most WI_MAX_INST k-mer instances):
 //   0. every k-mer instance of the chunk's records is expanded to its 128-bit
 //      entry key in LDS (one wave per record, one lane per k-mer);
 //   1. the instances are de-duplicated in an LDS table whose slots hold the index
@@ -1272,81 +1268,92 @@ __global__ void __launch_bounds__(256) k_stats(const DirEnt* __restrict__ dir, u
 }
 
 // ===========================================================================
-// k_query: the same LDS table as k_insert, but every instance keeps its own slot
-// (duplicates sit behind each other in the probe chain) and the partition's
-// entries add their count to the per-read sum of every instance they match
+// k_query: k_insert's structure (one wave per partition, persistent waves, descriptors), but the
+// table keeps every k-mer instance in its own slot (equal keys sit behind each other in the probe
+// chain), the partition's entries stream through it, and every hit adds the entry's count to the
+// instance's record; a record's total goes to its read with one atomic
 // (get_superkmer, Brisk.hpp:102-118; summed per read as counter.cpp:296-301 does).
-__global__ void __launch_bounds__(INSERT_BLOCK) k_query(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags,
-                                                        const u32* __restrict__ part_off, const u32* __restrict__ touched, u32 n_touched,
-                                                        IndexDev ix, unsigned long long* __restrict__ per_read_sum) {
-    __shared__ u64 s_key[2 * INS_MAX_INST];
-    __shared__ u32 s_tab[INS_TABLE];
-    __shared__ unsigned short s_irec[INS_MAX_INST];
-    __shared__ u32 s_pref[INS_MAX_REC + 1];
-    __shared__ u32 s_wave[INSERT_BLOCK / 64];
+__global__ void __launch_bounds__(64) k_query(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags,
+                                              const PartDesc* __restrict__ desc, u32 n_touched, IndexDev ix,
+                                              unsigned long long* __restrict__ per_read_sum, u32* __restrict__ work_counter) {
+    __shared__ u64 s_key[2 * WI_MAX_INST];
+    __shared__ u64 s_rec[WI_MAX_REC * 5];
+    __shared__ u32 s_tab[WI_TABLE];
+    __shared__ u32 s_pref[WI_MAX_REC + 1];
+    __shared__ u32 s_rsum[WI_MAX_REC];
+    __shared__ uint8_t s_irec[WI_MAX_INST];
 
-    const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (u32 t = blockIdx.x; t < n_touched; t += gridDim.x) {
-        const u32 part = touched[t];
-        const u32 r_begin = part_off[part], r_end = part_off[part + 1];
-        const u32 n_exist = ix.dir[part].cnt;
-        const unsigned long long off = ix.dir[part].off;
-        if (n_exist == 0) continue;
-        for (u32 rc = r_begin; rc < r_end;) {
-            __syncthreads();
-            const u32 avail = min(r_end - rc, (u32)INS_MAX_REC);
-            u64 my_hdr = 0;
-            if (tid < avail) my_hdr = rec[(u64)(rc + tid) * P.stride + P.nw];
-            u32 x = hdr_n(my_hdr);
-            for (int o = 1; o < 64; o <<= 1) {
-                const u32 y = __shfl_up(x, o, 64);
-                if ((int)lane >= o) x += y;
-            }
-            if (lane == 63) s_wave[wid] = x;
-            __syncthreads();
-            u32 woff = 0;
-            for (u32 j = 0; j < wid; j++) woff += s_wave[j];
-            x += woff;
-            if (tid < INS_MAX_REC) s_pref[tid + 1] = x;
-            if (tid == 0) s_pref[0] = 0;
-            __syncthreads();
-            const unsigned long long fb = __ballot(tid < avail && x <= INS_MAX_INST);
-            if (lane == 0) s_wave[wid] = (u32)__popcll(fb);
-            __syncthreads();
-            const u32 nrec = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-            const u32 ninst = s_pref[nrec];
-            for (u32 i = tid; i < INS_TABLE; i += INSERT_BLOCK) s_tab[i] = EMPTY_SLOT;
-            for (u32 r = wid; r < nrec; r += INSERT_BLOCK / 64) {
-                const u64* c = rec + (u64)(rc + r) * P.stride;
-                const u64 hdr = c[P.nw];
-                const u32 n = hdr_n(hdr);
-                if (lane < n) {
-                    const u128x key = make_key(P, hdr_bucket(hdr), record_kmer(P, c, n, lane), hdr_idx0(hdr) + lane);
-                    const u32 i = s_pref[r] + lane;
+    const u32 lane = threadIdx.x;
+    for (;;) {
+        u32 t0 = 0;
+        if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
+        t0 = __shfl(t0, 0, 64);
+        if (t0 >= n_touched) break;
+        const u32 t_end = min(t0 + WI_BATCH, n_touched);
+        for (u32 t = t0; t < t_end; t++) {
+            const PartDesc d = desc[t];
+            if (d.n_exist == 0) continue;  // nothing to find in an empty partition
+            const u32 r_end = d.r_begin + d.n_rec;
+            for (u32 rc = d.r_begin; rc < r_end;) {
+                const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
+                const RecRegs rr = load_rec_regs(P, rec, rc, avail, lane);
+                wave_sync();
+                if (lane < avail) {
+                    u64* dst = s_rec + lane * P.stride;
+                    dst[0] = rr.w0;
+                    dst[1] = rr.w1;
+                    if (P.stride > 2) dst[2] = rr.w2;
+                    if (P.stride > 3) dst[3] = rr.w3;
+                    if (P.stride > 4) dst[4] = rr.w4;
+                }
+                const u64 my_hdr = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
+                const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
+                const u32 x0 = wave_incl_scan(raw_n, lane);
+                const u32 nrec = (u32)__popcll(__ballot(lane < avail && x0 <= WI_MAX_INST));  // >= 1; a prefix
+                const u32 my_n = lane < nrec ? raw_n : 0;
+                const u32 ninst = __shfl(x0, nrec - 1, 64);
+                s_pref[lane + 1] = x0;
+                if (lane == 0) s_pref[0] = 0;
+                s_rsum[lane] = 0;
+#pragma unroll
+                for (u32 w = 0; w < WI_TS; w++) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                {
+                    const u32 start = x0 - raw_n;
+                    for (u32 j = 0; j < my_n; j++) s_irec[start + j] = (uint8_t)lane;
+                }
+                wave_sync();
+                // expand and give every instance a slot of its own
+                for (u32 i = lane; i < ninst; i += 64) {
+                    const u32 r = s_irec[i];
+                    const u64* c = s_rec + r * P.stride;
+                    const u64 hdr = c[P.nw];
+                    const u32 j = i - s_pref[r];
+                    const u128x key = make_key(P, hdr_bucket(hdr), record_kmer_lds<0>(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
                     s_key[2 * i] = key.lo;
                     s_key[2 * i + 1] = key.hi;
-                    s_irec[i] = (unsigned short)r;
+                    u32 h = hash_key32(key) & (WI_TABLE - 1);
+                    while (atomicCAS(&s_tab[h], EMPTY_SLOT, i) != EMPTY_SLOT) h = (h + 1) & (WI_TABLE - 1);
                 }
-            }
-            __syncthreads();
-            for (u32 i = tid; i < ninst; i += INSERT_BLOCK) {
-                u32 h = hash_key32(mk128(s_key[2 * i], s_key[2 * i + 1])) & (INS_TABLE - 1);
-                while (atomicCAS(&s_tab[h], EMPTY_SLOT, i) != EMPTY_SLOT) h = (h + 1) & (INS_TABLE - 1);
-            }
-            __syncthreads();
-            for (u32 e = tid; e < n_exist; e += INSERT_BLOCK) {
-                const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
-                const u32 cnt = ix.counts[off + e];
-                u32 h = hash_key32(key) & (INS_TABLE - 1);
-                for (;;) {
-                    const u32 v = s_tab[h];
-                    if (v == EMPTY_SLOT) break;
-                    if (s_key[2 * v] == key.lo && s_key[2 * v + 1] == key.hi)
-                        atomicAdd(&per_read_sum[tags[rc + s_irec[v]]], (unsigned long long)cnt);
-                    h = (h + 1) & (INS_TABLE - 1);
+                wave_sync();
+                // the partition's entries look their key up; every instance holding it gets the count
+                for (u32 e = lane; e < d.n_exist; e += 64) {
+                    const u128x key = mk128(ix.keys[2 * (d.off + e)], ix.keys[2 * (d.off + e) + 1]);
+                    const u32 cnt = ix.counts[d.off + e];
+                    u32 h = hash_key32(key) & (WI_TABLE - 1);
+                    for (;;) {
+                        const u32 v = s_tab[h];
+                        if (v == EMPTY_SLOT) break;
+                        if (s_key[2 * v] == key.lo && s_key[2 * v + 1] == key.hi) atomicAdd(&s_rsum[s_irec[v]], cnt);
+                        h = (h + 1) & (WI_TABLE - 1);
+                    }
                 }
+                wave_sync();
+                if (lane < nrec) {
+                    const u32 sum = s_rsum[lane];
+                    if (sum) atomicAdd(&per_read_sum[tags[rc + lane]], (unsigned long long)sum);
+                }
+                rc += nrec;
             }
-            rc += nrec;
         }
     }
 }
