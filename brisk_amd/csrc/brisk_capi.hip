@@ -59,6 +59,7 @@ struct brisk_hip_index {
     bool scan_v1 = false;       // BRISK_SCAN_V1=1: the plain restatement kernel
     bool entry_ids = false;
     bool use_vmm = false;
+    u64 arena_limit = 0;        // BRISK_ARENA_LIMIT (entries): artificial ceiling, for tests of the out-of-memory path
     VmBuf vm_keys, vm_counts, vm_ids;
     unsigned long long* d_id_counter = nullptr;
     DevBuf seq_buf;
@@ -213,6 +214,7 @@ void vm_free(VmBuf& b) {
 int ensure_arena(brisk_hip_index* h, u64 need_entries) {
     if (h->arena_used_host + need_entries <= h->arena_cap) return BRISK_HIP_OK;
     const u64 target = h->arena_used_host + need_entries;
+    if (h->arena_limit && target > h->arena_limit) return fail(h, BRISK_HIP_ENOMEM, "arena: BRISK_ARENA_LIMIT reached");
     if (h->use_vmm) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         u64 ncap = std::max<u64>(target, 1u << 16);
@@ -272,7 +274,19 @@ int prefix_partitions(brisk_hip_index* h, u64 n_bins) {
 
 // records (unordered, all owned by this index) -> index.  If have_hist, d_hist
 // already holds this batch's per-partition histogram (the scan filled it).
+int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist);
+
+// Records in any split are still a valid batch: when the single-pass arena reserve for a batch does not
+// fit the device (BRISK_HIP_ENOMEM is raised before anything is written), insert it as two halves.
 int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist) {
+    int rc = insert_records_once(h, d_rec, n_rec, have_hist);
+    if (rc != BRISK_HIP_ENOMEM || n_rec < 2) return rc;
+    const u64 half = n_rec / 2;
+    if ((rc = insert_records_impl(h, d_rec, half, false))) return rc;
+    return insert_records_impl(h, d_rec + half * h->P.stride, n_rec - half, false);
+}
+
+int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist) {
     if (n_rec == 0) return BRISK_HIP_OK;
     if (n_rec >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
     const BriskParams& P = h->P;
@@ -659,6 +673,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         {
             // reserve virtual ranges as large as the device's memory; physical pages follow demand
             size_t free_b = 0, total_b = 0;
+            if (const char* lim = getenv("BRISK_ARENA_LIMIT")) h->arena_limit = strtoull(lim, nullptr, 10);
             const char* novmm = getenv("BRISK_NO_VMM");
             if (!(novmm && novmm[0] == '1') && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
                 const u64 max_entries = total_b / 17;

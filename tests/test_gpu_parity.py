@@ -433,3 +433,22 @@ def test_mixed_insert_get_workload(B, O):
                 assert np.array_equal(ix.get_reads(nxt), O.index_query_reads(h, f2, o2))
         assert ix.checksum() == oracle.digest(*O.index_dump(h))
     O.index_free(h)
+
+
+def test_batch_splits_when_the_arena_reserve_does_not_fit(B, O, monkeypatch):
+    """The single-pass insert reserves arena for "every instance is new"; when that does not fit, the
+    batch is inserted in halves (nothing was written yet).  Also the copy-growth path without HIP VMM."""
+    rng = random.Random(17)
+    reads = _random_reads(rng, 2500, 15000)
+    k, m, b = 63, 21, 14
+    want = O.count(reads, k, m, b)
+    inst = sum(len(r) - k + 1 for r in reads)
+    monkeypatch.setenv("BRISK_ARENA_LIMIT", str(2560 * 32768 + inst // 2))  # the per-wave chunk slack plus half the pessimistic bound
+    assert gpu_count(B, reads, k, m, b) == want
+    monkeypatch.setenv("BRISK_ARENA_LIMIT", "1000")  # nothing fits: a clean error, not a crash
+    with pytest.raises(B.BriskHipError) as e:
+        gpu_count(B, reads, k, m, b)
+    assert e.value.code == 4
+    monkeypatch.delenv("BRISK_ARENA_LIMIT")
+    monkeypatch.setenv("BRISK_NO_VMM", "1")
+    assert gpu_count(B, reads, k, m, b, batches=4) == want
