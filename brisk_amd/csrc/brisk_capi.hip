@@ -68,7 +68,7 @@ struct brisk_hip_index {
     u64 arena_used_host = 0;
     IndexDev ix{};
     // scratch
-    DevBuf staging, parted, desc, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
+    DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
     u32* d_cur32 = nullptr;                // n_parts
@@ -141,6 +141,13 @@ inline u32 nblocks(u64 n, u32 per) { return (u32)((n + per - 1) / per); }
 int launch_check(brisk_hip_index* h, const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, BRISK_HIP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    static const bool sync_launches = getenv("BRISK_SYNC_LAUNCHES") != nullptr;  // debugging: name the kernel a device fault belongs to
+    if (sync_launches) {
+        fprintf(stderr, "[brisk_hip] %s ...", what);
+        e = hipStreamSynchronize(h->stream);
+        fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+        if (e != hipSuccess) return fail(h, BRISK_HIP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
     return BRISK_HIP_OK;
 }
 
@@ -303,6 +310,7 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         ProfScope ps(h, S_TOUCHED);
         hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
                            (u32*)(h->d_small + 2));
+        if (int lrc = launch_check(h, "k_touched")) return lrc;
     }
     if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
     {
@@ -320,6 +328,7 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
         hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched,
                            h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3);
+        if (int lrc = launch_check(h, "k_need")) return lrc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 3, h->d_small + 3, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));
@@ -341,28 +350,105 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
 }
 
 // scan reads -> records in d_rec (cap records).  n_rec_out on host after a sync.
+// one scan launch over n_items reads (or virtual reads when cc.vreads is set); counters are NOT reset here
+int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_items, const ScanOut& out, bool query_mode, bool plain,
+                const ChunkCtl& cc) {
+    ProfScope ps(h, S_SCAN);
+    if (plain) {  // sequence mode needs the minimizer values: the plain kernel carries them
+        hipLaunchKernelGGL(k_scan, dim3(nblocks(n_items, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_items, h->d_coef,
+                           out, query_mode ? 1 : 0);
+    } else {
+        const u32 bt = h->scan_waves * 64;
+        const dim3 grid(nblocks(n_items, bt)), block(bt);
+        const int qm = query_mode ? 1 : 0;
+        switch (h->scfg.nch) {  // unrolled table lookups for the common minimizer sizes
+            case 5: hipLaunchKernelGGL(k_scan2<5>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, qm, cc); break;
+            case 3: hipLaunchKernelGGL(k_scan2<3>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, qm, cc); break;
+            default: hipLaunchKernelGGL(k_scan2<0>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, qm, cc);
+        }
+    }
+    return launch_check(h, "k_scan");
+}
+
+// Scan a batch into d_rec.  Long sequences (insert mode only) are scanned as chunks, checked at the
+// seams and, if a seam does not match, re-scanned whole; *hist_valid tells whether d_hist still
+// describes exactly the records in d_rec.
 int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, u64* d_rec, u64 cap, bool with_hist,
-              bool query_mode, u32* d_tags, u64* n_rec_out, u64* d_ret = nullptr) {
+              bool query_mode, u32* d_tags, u64* n_rec_out, u64* d_ret = nullptr, u64 kmer_bound = 0, bool* hist_valid = nullptr) {
+    if (hist_valid) *hist_valid = with_hist;
     if (with_hist) HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
     ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret};
-    {
-        ProfScope ps(h, S_SCAN);
-        if (h->scan_v1 || d_ret) {  // sequence mode needs the minimizer values: the plain kernel carries them
-            hipLaunchKernelGGL(k_scan, dim3(nblocks(n_reads, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_reads,
-                               h->d_coef, out, query_mode ? 1 : 0);
-        } else {
-            const u32 bt = h->scan_waves * 64;
-            const dim3 grid(nblocks(n_reads, bt)), block(bt);
-            const int qm = query_mode ? 1 : 0;
-            switch (h->scfg.nch) {  // unrolled table lookups for the common minimizer sizes
-                case 5: hipLaunchKernelGGL(k_scan2<5>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads, h->d_tabs, out, qm); break;
-                case 3: hipLaunchKernelGGL(k_scan2<3>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads, h->d_tabs, out, qm); break;
-                default: hipLaunchKernelGGL(k_scan2<0>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_reads, h->d_tabs, out, qm);
-            }
+    const bool plain = h->scan_v1 || d_ret;
+    int rc;
+    u32 n_vr = 0;
+    const bool may_chunk = !plain && !query_mode && !d_tags && kmer_bound > SCAN_LONG;
+    VRead* d_vr = nullptr;
+    ChunkState *d_spec = nullptr, *d_truth = nullptr;
+    u32* d_bad = nullptr;
+    u64 cap_vr = 0;
+    if (may_chunk) {
+        cap_vr = kmer_bound / SCAN_CHUNK + kmer_bound / SCAN_LONG + 2;
+        const size_t bytes = cap_vr * sizeof(VRead) + (2 * cap_vr + 1) * sizeof(ChunkState) + (n_reads + 1) * 4;
+        if ((rc = ensure(h, h->chunk_buf, bytes))) return rc;
+        d_vr = (VRead*)h->chunk_buf.p;
+        d_spec = (ChunkState*)(d_vr + cap_vr);
+        d_truth = d_spec + cap_vr;
+        d_bad = (u32*)(d_truth + cap_vr + 1);
+        HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
+        hipLaunchKernelGGL(k_plan_chunks, dim3(nblocks(n_reads, 256)), dim3(256), 0, h->stream, d_starts, n_reads, h->P.k, h->P.w, d_vr, (u32)cap_vr,
+                           (u32*)(h->d_small + 7));
+        if (int lrc = launch_check(h, "k_plan_chunks")) return lrc;
+        HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n_vr = (u32)h->h_small[7];
+        if (n_vr > cap_vr) return fail(h, BRISK_HIP_EHIP, "chunk plan exceeds its bound");
+    }
+    ChunkCtl cc{nullptr, nullptr, nullptr, n_vr ? SCAN_LONG : 0u};
+    if ((rc = launch_scan(h, d_packed, d_starts, n_reads, out, query_mode, plain, cc))) return rc;
+    if (n_vr) {
+        // records of the short reads are in [0, n1); the chunked launch appends after them and tags its records
+        HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const u64 n1 = std::min<u64>(h->h_small[0], cap);
+        if ((rc = ensure(h, h->tags_a, cap * 4))) return rc;
+        HIPCHK(h, hipMemsetAsync(d_spec, 0, (2 * cap_vr + 1) * sizeof(ChunkState), h->stream));
+        HIPCHK(h, hipMemsetAsync(d_bad, 0, (n_reads + 1) * 4, h->stream));
+        ScanOut out2 = out;
+        out2.tag = (u32*)h->tags_a.p;
+        ChunkCtl c2{d_vr, d_spec, d_truth, 0u};
+        if ((rc = launch_scan(h, d_packed, d_starts, n_vr, out2, false, false, c2))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
+        hipLaunchKernelGGL(k_verify_chunks, dim3(nblocks(n_vr, 256)), dim3(256), 0, h->stream, d_vr, d_spec, d_truth, n_vr, d_bad, (u32*)(h->d_small + 7));
+        if (int lrc = launch_check(h, "k_verify_chunks")) return lrc;
+        HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const u32 n_bad = (u32)h->h_small[7];
+        if (n_bad && !(u32)h->h_small[1]) {
+            // a seam did not match: drop what the chunks of those sequences emitted and scan them whole (one lane each)
+            const u64 n2 = std::min<u64>(h->h_small[0], cap);
+            if ((rc = ensure(h, h->parted, (n2 - n1 + 1) * h->P.stride * 8))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
+            hipLaunchKernelGGL(k_filter_records, dim3(nblocks(n2 - n1, 256)), dim3(256), 0, h->stream, h->P, d_rec, (const u32*)h->tags_a.p, n1, n2, d_bad,
+                               (u64*)h->parted.p, h->d_small + 6);
+            if (int lrc = launch_check(h, "k_filter_records")) return lrc;
+            HIPCHK(h, hipMemcpyAsync(h->h_small + 6, h->d_small + 6, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const u64 kept = h->h_small[6];
+            if (kept) HIPCHK(h, hipMemcpyAsync(d_rec + n1 * h->P.stride, h->parted.p, kept * h->P.stride * 8, hipMemcpyDeviceToDevice, h->stream));
+            h->h_small[6] = n1 + kept;  // pinned: stays untouched until the copy below has run
+            HIPCHK(h, hipMemcpyAsync(h->d_small, h->h_small + 6, 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
+            hipLaunchKernelGGL(k_bad_vreads, dim3(nblocks(n_reads, 256)), dim3(256), 0, h->stream, d_starts, n_reads, d_bad, d_vr, (u32*)(h->d_small + 7));
+            if (int lrc = launch_check(h, "k_bad_vreads")) return lrc;
+            ScanOut out3 = out;
+            out3.hist = nullptr;  // the histogram is rebuilt from the final records
+            ChunkCtl c3{d_vr, d_spec, d_truth, 0u};
+            if ((rc = launch_scan(h, d_packed, d_starts, n_bad, out3, false, false, c3))) return rc;
+            if (hist_valid) *hist_valid = false;
         }
-        int rc;
-        if ((rc = launch_check(h, "k_scan"))) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -377,6 +463,7 @@ int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out) 
         ProfScope ps(h, S_COUNT);
         const u32 grid = std::min<u32>(nblocks(n_reads, 256), 4096);
         hipLaunchKernelGGL(k_count_kmers, dim3(grid ? grid : 1), dim3(256), 0, h->stream, d_starts, n_reads, h->P.k, h->d_small + 4);
+        if (int lrc = launch_check(h, "k_count_kmers")) return lrc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->d_small + 4, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -386,7 +473,7 @@ int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out) 
 
 // scan a batch into the staging buffer, retrying once with the exact bound
 int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool with_hist, bool query_mode,
-                    u64* n_rec_out) {
+                    u64* n_rec_out, bool* hist_valid = nullptr) {
     int rc;
     u64 bound = 0;
     if ((rc = count_kmers(h, d_starts, n_reads, &bound))) return rc;
@@ -402,7 +489,7 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
             if ((rc = ensure(h, h->tags_a, cap * 4))) return rc;
             tags = (u32*)h->tags_a.p;
         }
-        rc = scan_impl(h, d_packed, d_starts, n_reads, (u64*)h->staging.p, cap, with_hist, query_mode, tags, n_rec_out);
+        rc = scan_impl(h, d_packed, d_starts, n_reads, (u64*)h->staging.p, cap, with_hist, query_mode, tags, n_rec_out, nullptr, bound, hist_valid);
         if (rc != BRISK_HIP_ECAPACITY) return rc;
         cap = bound;
     }
@@ -414,8 +501,9 @@ int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_sta
         const u64 nb = std::min<u64>(h->max_batch_reads, n_reads - r0);
         u64 n_rec = 0;
         int rc;
-        if ((rc = scan_to_staging(h, d_packed, d_starts + r0, nb, true, false, &n_rec))) return rc;
-        if ((rc = insert_records_impl(h, (const u64*)h->staging.p, n_rec, true))) return rc;
+        bool hist_ok = true;
+        if ((rc = scan_to_staging(h, d_packed, d_starts + r0, nb, true, false, &n_rec, &hist_ok))) return rc;
+        if ((rc = insert_records_impl(h, (const u64*)h->staging.p, n_rec, hist_ok))) return rc;
     }
     return BRISK_HIP_OK;
 }
@@ -431,6 +519,7 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
     hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
                        (u32*)(h->d_small + 2));
+    if (int lrc = launch_check(h, "k_touched")) return lrc;
     if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
     if ((rc = ensure(h, h->tags_b, n_rec * 4))) return rc;
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, (const u64*)h->staging.p, n_rec, h->d_cur32,
@@ -443,6 +532,7 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
     hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched, h->ix.dir,
                        (PartDesc*)h->desc.p, h->d_small + 3);
+    if (int lrc = launch_check(h, "k_need")) return lrc;
     {
         ProfScope ps(h, S_QUERY);
         HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
@@ -501,8 +591,9 @@ int drain_profile(brisk_hip_index* h) {
 }
 
 void free_all(brisk_hip_index* h) {
+    hipStreamSynchronize(h->stream);  // nothing of ours may be in flight when the arena is unmapped
     auto fr = [](void* p) { if (p) hipFree(p); };
-    for (DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+    for (DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);
@@ -833,6 +924,7 @@ static int enumerate_impl(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo
         h->h_dir_cnt.resize(h->n_parts);
         // d_cur32 is per-batch scratch, free between batches
         hipLaunchKernelGGL(k_dir_counts, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->ix.dir, h->n_parts, h->d_cur32);
+        if (int lrc = launch_check(h, "k_dir_counts")) return lrc;
         HIPCHK(h, hipMemcpyAsync(h->h_dir_cnt.data(), h->d_cur32, h->n_parts * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->dir_snapshot_valid = true;
@@ -900,9 +992,11 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (h->P.shift > 6) {  // partitions wider than 64 buckets: rebuild the bitmap from the entries
         HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, bit_words * 4, h->stream));
         hipLaunchKernelGGL(k_bucket_bits, dim3((u32)std::min<u64>(h->n_parts, 4096)), dim3(256), 0, h->stream, h->P, h->ix, (u32)h->n_parts);
+        if (int lrc = launch_check(h, "k_bucket_bits")) return lrc;
     }
     HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 24, h->stream));
     hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, h->stream, h->ix.dir, h->n_parts, h->ix.bucket_bits, bit_words, h->ix.stats);
+    if (int lrc = launch_check(h, "k_stats")) return lrc;
     unsigned long long st[4];
     HIPCHK(h, hipMemcpyAsync(st, h->ix.stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -912,7 +1006,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (nb_skmers) *nb_skmers = h->nb_skmers;
     if (memory_bytes) {
         u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
-        for (const DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
+        for (const DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
                                 &h->enum_out, &h->lookup_buf})
             m += b->bytes;
         *memory_bytes = m;
@@ -954,7 +1048,10 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     *n_records = 0;
     if (!n_reads) return BRISK_HIP_OK;
     u64 n = 0;
-    int rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, false, nullptr, &n);
+    u64 bound = 0;
+    int rc = count_kmers(h, d_starts, n_reads, &bound);
+    if (rc) return rc;
+    rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, false, nullptr, &n, nullptr, bound);
     *n_records = n;
     return rc;
 }
@@ -972,6 +1069,7 @@ BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_reco
     {
         ProfScope ps(h, S_HIST);
         hipLaunchKernelGGL(k_owner_hist, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_hist);
+        if (int lrc = launch_check(h, "k_owner_hist")) return lrc;
     }
     if ((rc = prefix_partitions(h, no))) return rc;
     {

@@ -349,6 +349,102 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
     return v;
 }
 
+// ---- long sequences: scanned as overlapping chunks, each chunk a "virtual read" ----------------
+// The enumerator's state (minimizer key, its position, its strand) at a step depends on history, so a
+// chunk starts SCAN_WARMUP steps early from a fresh state, emits only the vectors that start inside
+// its own window [emit_from, emit_until), and records the state it had reached at emit_from; the
+// previous chunk records the state it had at the same step.  Equal states => everything the chunk
+// emitted is exactly what one sequential pass emits.  A sequence with a mismatch (long runs where no
+// new minimum ever arrives keep two runs out of phase) is re-scanned whole by one lane.
+#define SCAN_LONG 8192u     // sequences with more k-mers than this are chunked
+#define SCAN_CHUNK 4096u    // steps (k-mers) per chunk
+#define SCAN_WARMUP 512u    // steps a chunk runs before its window
+struct VRead {
+    u64 q0;          // stream index of the virtual read's first nt
+    u32 len;         // nts
+    u32 emit_from;   // local step of the first vector start that belongs to this chunk
+    u32 emit_until;  // local step bound (exclusive); ~0u: to the end of the sequence
+    u32 read;        // index of the sequence in the batch
+    u32 flags;       // 1: starts at the sequence's first nt, 2: runs to its last k-mer
+    u32 pad;
+};
+struct ChunkState {
+    u64 hash;
+    u32 pos_rev;     // mini_pos | reversed << 31
+    u32 set;
+};
+struct ChunkCtl {
+    const VRead* vreads;   // null: whole reads from `starts`
+    ChunkState* spec;      // [n_vreads]   state a chunk reached at its emit_from
+    ChunkState* truth;     // [n_vreads+1] state the previous chunk had at the same step
+    u32 long_limit;        // whole-read launch: skip reads with more k-mers than this (0: none)
+};
+
+// one thread per read: plan the chunks of long reads (consecutive slots per read)
+__global__ void __launch_bounds__(256) k_plan_chunks(const u64* __restrict__ starts, u64 n_reads, u32 k, u32 w, VRead* __restrict__ vreads,
+                                                     u32 cap, u32* __restrict__ n_vreads) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const u64 q0 = starts[r], len = starts[r + 1] - q0;
+    if (len < k) return;
+    const u64 nk = len - k + 1;
+    if (nk <= SCAN_LONG) return;
+    const u32 nc = (u32)((nk + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    const u32 base = atomicAdd(n_vreads, nc);
+    if (base + nc > cap) return;  // cannot happen: cap is the bound the host computed
+    for (u32 c = 0; c < nc; c++) {
+        const u64 b0 = (u64)c * SCAN_CHUNK, b1 = b0 + SCAN_CHUNK;
+        const u64 s0 = c == 0 ? 0 : b0 - SCAN_WARMUP;
+        const bool last = b1 >= nk;
+        const u64 end_step = last ? nk : (b1 + w + 2 < nk ? b1 + w + 2 : nk);
+        VRead v;
+        v.q0 = q0 + s0;
+        v.len = (u32)(end_step - s0 + k - 1);
+        v.emit_from = (u32)(b0 - s0);
+        v.emit_until = last ? 0xffffffffu : (u32)(b1 - s0);
+        v.read = (u32)r;
+        v.flags = (c == 0 ? 1u : 0u) | (end_step == nk ? 2u : 0u);  // bit 1: this virtual read runs to the sequence's last k-mer
+        v.pad = 0;
+        vreads[base + c] = v;
+    }
+}
+// chunk c's speculative start state must equal what chunk c-1 had at that step
+__global__ void __launch_bounds__(256) k_verify_chunks(const VRead* __restrict__ vreads, const ChunkState* __restrict__ spec,
+                                                       const ChunkState* __restrict__ truth, u32 n_vreads, u32* __restrict__ bad_read, u32* __restrict__ n_bad) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vreads) return;
+    const VRead v = vreads[i];
+    if (v.flags & 1u) return;
+    const ChunkState a = spec[i], b = truth[i];
+    if (!(a.set && b.set && a.hash == b.hash && a.pos_rev == b.pos_rev)) {
+        if (atomicExch(&bad_read[v.read], 1u) == 0u) atomicAdd(n_bad, 1u);
+    }
+}
+// drop the records of sequences that must be re-scanned; whole-read descriptors for those sequences
+__global__ void __launch_bounds__(256) k_filter_records(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags, u64 first, u64 n_rec,
+                                                        const u32* __restrict__ bad_read, u64* __restrict__ out, unsigned long long* __restrict__ n_out) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    if (bad_read[tags[i]]) return;
+    const unsigned long long slot = atomicAdd(n_out, 1ull);
+    for (u32 j = 0; j < P.stride; j++) out[slot * P.stride + j] = rec[i * P.stride + j];
+}
+__global__ void __launch_bounds__(256) k_bad_vreads(const u64* __restrict__ starts, u64 n_reads, const u32* __restrict__ bad_read,
+                                                    VRead* __restrict__ vreads, u32* __restrict__ n_vreads) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || !bad_read[r]) return;
+    const u32 slot = atomicAdd(n_vreads, 1u);
+    VRead v;
+    v.q0 = starts[r];
+    v.len = (u32)(starts[r + 1] - v.q0);
+    v.emit_from = 0;
+    v.emit_until = 0xffffffffu;
+    v.read = (u32)r;
+    v.flags = 3u;
+    v.pad = 0;
+    vreads[slot] = v;
+}
+
 // closed form of get_minimizer's fold (Kmers.cpp:377-405) given the first and last window
 // holding the minimum key, their `reversed` flags and K-m
 __device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first, bool rev_last, u32 Km, bool canon_if_needed_known, bool canon,
@@ -370,7 +466,7 @@ __device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first
 
 template <int NCH>
 __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
-                                                u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, int query_mode) {
+                                                u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, int query_mode, ChunkCtl cc) {
     extern __shared__ double smem_d[];
     double* s_coef = smem_d;             // 128
     double* s_tabs = smem_d + 128;       // 2*nch*256
@@ -388,9 +484,23 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     const u64 M = P.m_mask;
     const u64 r = (u64)blockIdx.x * blockDim.x + tid;
     u64 q0 = 0, len = 0;
+    u32 emit_from = 0, emit_until = 0xffffffffu, tagval = (u32)r;
+    bool seq_first = true, seq_last = true;
     if (r < n_reads) {
-        q0 = starts[r];
-        len = starts[r + 1] - q0;
+        if (cc.vreads) {
+            const VRead v = cc.vreads[r];
+            q0 = v.q0;
+            len = v.len;
+            emit_from = v.emit_from;
+            emit_until = v.emit_until;
+            tagval = v.read;
+            seq_first = v.flags & 1u;
+            seq_last = v.flags & 2u;
+        } else {
+            q0 = starts[r];
+            len = starts[r + 1] - q0;
+            if (cc.long_limit && len >= k && len - k + 1 > cc.long_limit) len = 0;  // a chunked launch takes this one
+        }
     }
     const bool live = len >= k;  // counter.cpp:233-235
     u32 nk = live ? (u32)(len - k + 1) : 0;
@@ -479,6 +589,10 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     const u32 Km = k - m;
     for (u32 p = 0; p < max_nk; p++) {
         const bool act = p < nk && !dead;
+        if (cc.vreads && live) {  // the enumerator state before step p, for the chunk-seam check
+            if (p == emit_from && !seq_first) cc.spec[r] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
+            if (p == emit_until) cc.truth[r + 1] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
+        }
         if ((p & 31) == 0 && p < nk) {
             const u32 left = (u32)(len - (k - 1 + p));
             const u32 cnt = left < 32 ? left : 32;
@@ -500,7 +614,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
         const bool closed = expired || newmin;
         // the vector closed by this step (Kmers.cpp:585-588); a close at p == 0 is ignored (:590-592)
-        bool push = closed && p > 0;
+        bool push = closed && p > 0 && p0 >= emit_from && p0 < emit_until;  // a chunk emits the vectors that start in its window
         if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) {  // counter.cpp:304-306: returned minimizer == 0
             push = false;
             dead = true;
@@ -511,7 +625,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
                 const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
                 q_start[at] = q0 + p0;
                 q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16);
-                q_tag[at] = (u32)r;
+                q_tag[at] = tagval;
                 n_emitted++;
             }
             qcount += (u32)__popcll(bal);
@@ -593,14 +707,15 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     }
     // the last vector of every read (Kmers.cpp:596-601)
     {
-        bool push = live && !dead && n > 0;
+        // the sequence's true end closes the open vector; it belongs to the chunk in whose window it started
+        bool push = live && !dead && n > 0 && seq_last && p0 >= emit_from && p0 < emit_until;
         if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) push = false;
         const unsigned long long bal = __ballot(push);
         if (push) {
             const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
             q_start[at] = q0 + p0;
             q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16);
-            q_tag[at] = (u32)r;
+            q_tag[at] = tagval;
         }
         qcount += (u32)__popcll(bal);
     }

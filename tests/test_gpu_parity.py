@@ -330,6 +330,38 @@ def test_long_sequences_and_ragged_lengths(B, O):
         assert gpu_count(B, reads, k, m, b) == O.count(reads, k, m, b)
 
 
+def test_chromosome_length_sequences_are_scanned_in_chunks(B, O):
+    """Sequences with more than 8192 k-mers are scanned as overlapping chunks whose seams are verified
+    against the sequential state; sequences whose seams cannot match (long runs without a new minimum:
+    homopolymers, short tandem repeats) fall back to one lane.  Either way: bit-exact."""
+    rng = random.Random(2024)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    seqs = [rnd(300_017), rnd(8192 + 62), rnd(8192 + 63), rnd(8192 + 64), rnd(12_288 + 62), rnd(40_000)]
+    seqs += ["A" * 30_000, ("ACGTTGCA" * 4000), rnd(15_000) + "T" * 20_000 + rnd(15_000), (rnd(37) * 1000)]
+    seqs += _random_reads(rng, 200, 3000)  # short reads in the same batch
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    seqs.append(rc(seqs[0][1000:150_000]))
+    for k, m, b in ((63, 21, 14), (31, 11, 11), (31, 11, 4)):
+        assert gpu_count(B, seqs, k, m, b) == O.count(seqs, k, m, b), (k, m, b)
+    # and as two batches, through the records API used for sharding (scan -> insert_records)
+    import torch
+    k, m, b = 63, 21, 14
+    flat, offs = oracle.pack_reads(seqs)
+    with B.BriskHip(k, m, b) as ix:
+        d_bases = torch.from_numpy(flat).cuda()
+        d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+        d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        ix.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        bound = ix.scan_bound(d_starts.data_ptr(), len(seqs))
+        d_rec = torch.zeros(bound * ix.record_words, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), len(seqs), d_rec.data_ptr(), bound)
+        ix.insert_records(d_rec.data_ptr(), n_rec)
+        st = ix.stats()
+        assert (oracle.multiset_lines(*ix.enumerate(), k), st["nb_kmers"], st["nb_buckets"]) == O.count(seqs, k, m, b)
+
+
 def test_per_call_api_entry_ids(B, O):
     """The facade's per-call path: scan_sequence == the enumerator stream (incl. the returned
     minimizer values), upsert/find/enumerate_ids == insert_superkmer/get/next with DATA on the host."""
