@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -68,6 +69,7 @@ struct brisk_hip_index {
     u64 arena_used_host = 0;
     IndexDev ix{};
     // scratch
+    DevBuf route_buf;
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
@@ -215,6 +217,60 @@ void vm_free(VmBuf& b) {
     b = VmBuf{};
 }
 
+// Arenas of destroyed indexes are kept (one per process) with their first mapped pieces and handed to
+// the next index on the same device: creating and destroying indexes in a loop then neither pays for
+// reserve/map/unmap each time nor re-maps fresh physical memory at a just-released virtual address.
+struct VmSet {
+    int device = -1;
+    VmBuf keys, counts, ids;
+};
+std::mutex g_pool_mu;
+std::vector<VmSet> g_pool;
+constexpr size_t kPoolKeepEntries = (size_t)1 << 30;  // entries a pooled arena keeps mapped (16 GiB of keys)
+
+void vm_trim(VmBuf& b, size_t keep_bytes) {  // unmap tail pieces beyond keep_bytes (the first piece always stays)
+    while (b.handles.size() > 1 && b.mapped - b.sizes.back() >= keep_bytes) {
+        const size_t sz = b.sizes.back();
+        hipMemUnmap(b.base + b.mapped - sz, sz);
+        hipMemRelease(b.handles.back());
+        b.handles.pop_back();
+        b.sizes.pop_back();
+        b.mapped -= sz;
+    }
+}
+bool pool_take(int device, bool want_ids, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++) {
+        if (g_pool[i].device != device) continue;
+        keys = g_pool[i].keys;
+        counts = g_pool[i].counts;
+        ids = g_pool[i].ids;
+        g_pool.erase(g_pool.begin() + i);
+        if (!want_ids) vm_free(ids);
+        return true;
+    }
+    return false;
+}
+void pool_give(int device, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool.empty() || !keys.base || !counts.base) {
+        vm_free(keys);
+        vm_free(counts);
+        vm_free(ids);
+        return;
+    }
+    vm_trim(keys, kPoolKeepEntries * 16);
+    vm_trim(counts, kPoolKeepEntries);
+    vm_trim(ids, kPoolKeepEntries * 4);
+    VmSet s;
+    s.device = device;
+    s.keys = keys;
+    s.counts = counts;
+    s.ids = ids;
+    g_pool.push_back(s);
+    keys = counts = ids = VmBuf{};
+}
+
 // arena growth.  With virtual memory management: map more physical memory behind the reserved
 // ranges (no copy).  Without it (reservation failed at create): offsets are bump-allocated, so
 // the used prefix moves verbatim into a larger allocation.
@@ -308,7 +364,7 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 16, h->stream));
     {
         ProfScope ps(h, S_TOUCHED);
-        hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
+        hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 1024 * TOUCHED_ITEMS)), dim3(1024), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
                            (u32*)(h->d_small + 2));
         if (int lrc = launch_check(h, "k_touched")) return lrc;
     }
@@ -326,7 +382,7 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     {
         ProfScope ps(h, S_TOUCHED);
         if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
-        hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched,
+        hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched,
                            h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3);
         if (int lrc = launch_check(h, "k_need")) return lrc;
     }
@@ -517,7 +573,7 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     if (n_rec == 0) return BRISK_HIP_OK;
     if ((rc = prefix_partitions(h, h->n_parts))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
-    hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 256)), dim3(256), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
+    hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 1024 * TOUCHED_ITEMS)), dim3(1024), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
                        (u32*)(h->d_small + 2));
     if (int lrc = launch_check(h, "k_touched")) return lrc;
     if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
@@ -530,7 +586,7 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     if (n_touched == 0) return BRISK_HIP_OK;
     if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
-    hipLaunchKernelGGL(k_need, dim3(nblocks(n_touched, 256)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched, h->ix.dir,
+    hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched, h->ix.dir,
                        (PartDesc*)h->desc.p, h->d_small + 3);
     if (int lrc = launch_check(h, "k_need")) return lrc;
     {
@@ -593,15 +649,13 @@ int drain_profile(brisk_hip_index* h) {
 void free_all(brisk_hip_index* h) {
     hipStreamSynchronize(h->stream);  // nothing of ours may be in flight when the arena is unmapped
     auto fr = [](void* p) { if (p) hipFree(p); };
-    for (DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+    for (DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);
     fr(h->d_tabs);
     if (h->use_vmm) {
-        vm_free(h->vm_keys);
-        vm_free(h->vm_counts);
-        vm_free(h->vm_ids);
+        pool_give(h->device, h->vm_keys, h->vm_counts, h->vm_ids);
     } else {
         fr(h->ix.keys);
         fr(h->ix.counts);
@@ -672,6 +726,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     P.n_owners = o.n_owners ? o.n_owners : 1;
     P.owner_rank = o.owner_rank;
     if (P.owner_rank >= P.n_owners) { delete h; return BRISK_HIP_EINVAL; }
+    if (P.n_owners > ROUTE_MAX_OWNERS) { delete h; return BRISK_HIP_EUNSUPPORTED; }  // routing keeps per-owner cursors in LDS
     P.m_mask = (1ull << (2 * m)) - 1;
     P.bucket_mask = (1ull << (2 * b)) - 1;
     h->n_parts = 1ull << P.part_bits;
@@ -697,11 +752,9 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             ScanCfg& c = h->scfg;
             c.nlow = std::min<u32>(32, k);
             c.nlow1 = std::min<u32>(32, k - 1);
-            c.R = c.nlow - m + 1;
-            c.R_init = c.nlow1 - m + 1;
-            c.pitch = c.R | 1;
             c.nch = (m - 1 + 3) / 4;
-            c.qcap = 128;
+            c.qcap = 320;  // > 4 super-k-mers per lane before a mid-read flush
+            if (const char* e = getenv("BRISK_SCAN_QCAP")) c.qcap = (u32)std::max(128, atoi(e));
             const u32 n_tab = 128 + 2 * c.nch * 256;
             std::vector<double> tabs(n_tab, 0.0);
             for (u32 i = 0; i < 4u * m; i++) tabs[i] = coef_table[i];
@@ -716,11 +769,12 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             HIPCHK(h, hipMalloc((void**)&h->d_tabs, n_tab * sizeof(double)));
             HIPCHK(h, hipMemcpyAsync(h->d_tabs, tabs.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            const size_t per_wave = (size_t)(64 * c.pitch + 2 * c.qcap) * 8, fixed = (size_t)n_tab * 8;
+            // LDS: the class tables once per block, an emit queue per wave.  Eight waves per block, two blocks per CU.
+            const size_t per_wave = (size_t)(2 * c.qcap) * 8, fixed = (size_t)(n_tab + 9) * 8;
             const size_t lds_max = 160 * 1024;
-            u32 wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);
-            if (wv >= 8 && wv < 16) wv = 8;  // prefer a block size that divides the CU's wave slots
-            if (wv < 1) return fail(h, BRISK_HIP_EUNSUPPORTED, "scan state does not fit LDS");
+            u32 wv = 8;  // 2 blocks per CU, 4 waves per SIMD; block sizes that are not a multiple of 4 waves place badly
+            if (2 * (fixed + wv * per_wave) > lds_max) wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);  // big m: one block per CU
+            if (const char* e = getenv("BRISK_SCAN_WAVES")) wv = (u32)std::min(16, std::max(1, atoi(e)));
             h->scan_waves = wv;
             h->scan_lds = fixed + wv * per_wave;
             // the attribute is per function, not per handle: never lower it for a handle created earlier
@@ -768,8 +822,9 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             const char* novmm = getenv("BRISK_NO_VMM");
             if (!(novmm && novmm[0] == '1') && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
                 const u64 max_entries = total_b / 17;
-                if (vm_reserve(h, h->vm_keys, max_entries * 16) == BRISK_HIP_OK && vm_reserve(h, h->vm_counts, max_entries) == BRISK_HIP_OK &&
-                    (!h->entry_ids || vm_reserve(h, h->vm_ids, max_entries * 4) == BRISK_HIP_OK)) {
+                const bool pooled = pool_take(h->device, h->entry_ids, h->vm_keys, h->vm_counts, h->vm_ids);
+                if ((pooled || (vm_reserve(h, h->vm_keys, max_entries * 16) == BRISK_HIP_OK && vm_reserve(h, h->vm_counts, max_entries) == BRISK_HIP_OK)) &&
+                    (!h->entry_ids || h->vm_ids.base || vm_reserve(h, h->vm_ids, max_entries * 4) == BRISK_HIP_OK)) {
                     h->use_vmm = true;
                 } else {
                     vm_free(h->vm_keys);
@@ -1006,7 +1061,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (nb_skmers) *nb_skmers = h->nb_skmers;
     if (memory_bytes) {
         u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
-        for (const DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
+        for (const DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
                                 &h->enum_out, &h->lookup_buf})
             m += b->bytes;
         *memory_bytes = m;
@@ -1065,16 +1120,21 @@ BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_reco
     if (n_records >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
     if (no > h->n_parts) return fail(h, BRISK_HIP_EINVAL, "more owners than partitions");
     int rc;
+    const u32 grid = std::min<u32>(ROUTE_BLOCKS, nblocks(n_records, 256));
+    const u64 chunk = ((n_records + grid - 1) / grid + 255) / 256 * 256;  // records per block, whole 256-record tiles
+    if ((rc = ensure(h, h->route_buf, (size_t)grid * no * 4))) return rc;
+    u32* d_block = (u32*)h->route_buf.p;
     HIPCHK(h, hipMemsetAsync(h->d_hist, 0, ((u64)no + 1) * 8, h->stream));
     {
         ProfScope ps(h, S_HIST);
-        hipLaunchKernelGGL(k_owner_hist, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_hist);
+        hipLaunchKernelGGL(k_owner_hist, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, h->d_hist);
         if (int lrc = launch_check(h, "k_owner_hist")) return lrc;
+        hipLaunchKernelGGL(k_owner_offsets, dim3(1), dim3(ROUTE_MAX_OWNERS), 0, h->stream, no, grid, h->d_hist, d_block, h->d_off);
+        if (int lrc = launch_check(h, "k_owner_offsets")) return lrc;
     }
-    if ((rc = prefix_partitions(h, no))) return rc;
     {
         ProfScope ps(h, S_SCATTER);
-        hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_cur32, d_out);
+        hipLaunchKernelGGL(k_owner_scatter, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_out);
         if ((rc = launch_check(h, "k_owner_scatter"))) return rc;
     }
     std::vector<u32> off(no + 1);

@@ -167,8 +167,12 @@ __device__ MiniState rescan_minimizer(const u32* __restrict__ packed, u64 q, u32
 // Build and append the record of one super-k-mer: k-mers at read positions
 // [p0, p0+n), vector reversed if `rev` (Kmers.cpp:554-556,597-599); idx_end is
 // the minimizer_idx of the LAST element of the returned vector.
-__device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
-                            u32 idx_end, const ScanOut& out, u32 tag, u64 ret = 0) {
+__device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
+                               u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
+    if (slot >= out.cap) {
+        *out.overflow = 1;
+        return;
+    }
     const u32 L = P.k + n - 1;
     W4 S = load_span(packed, q0 + p0, L);
     if (rev) S = w4_rc(S, L);
@@ -185,11 +189,6 @@ __device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed
     const W4 lowm = w4_mask(2 * cut);
     const W4 C = w4_or(w4_andn(w4_shr(S, 2 * P.b), lowm), w4_and(S, lowm));
 
-    const unsigned long long slot = atomicAdd(out.n_rec, 1ull);
-    if (slot >= out.cap) {
-        *out.overflow = 1;
-        return;
-    }
     u64* r = out.rec + slot * P.stride;
     r[0] = C.w0;
     if (P.nw > 1) r[1] = C.w1;
@@ -200,6 +199,10 @@ __device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed
     if (out.tag) out.tag[slot] = tag;
     if (out.ret) out.ret[slot] = ret;
     if (out.hist) atomicAdd(&out.hist[bucket >> P.shift], 1ull | ((unsigned long long)n << 32));
+}
+__device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
+                            u32 idx_end, const ScanOut& out, u32 tag, u64 ret = 0) {
+    emit_record_at(P, packed, q0, p0, n, rev, idx_end, out, tag, ret, atomicAdd(out.n_rec, 1ull));
 }
 
 // query_mode: stop after the first super-k-mer whose returned minimizer is 0,
@@ -286,18 +289,14 @@ __device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1u
 //   * one lane per read steps the candidate m-mer; its order key is a table-driven
 //     decycling class (4-nt chunk sums in LDS, exact fold only inside a 1e-9 guard
 //     band around +-eps) plus the integer mixer;
-//   * the last R keys of every lane sit in an LDS ring, so a re-scan (get_minimizer,
-//     Kmers.cpp:367-408) reuses them for the windows that lie inside the low 64 bits
-//     and computes only the "fake" zero-padded windows (F2);
-//   * a re-scan is done by the whole wave, one window per lane, using the closed form
-//     of the tie rules (first and last position of the minimum key);
+//   * a re-scan (get_minimizer, Kmers.cpp:367-408) is done by a half-wave, one window per lane
+//     straight from the k-mer's low 64 bits (zero-padded "fake" windows included, F2), two
+//     k-mers per round, using the closed form of the tie rules (first and last position of
+//     the minimum key);
 //   * closed super-k-mers are queued in LDS and turned into records by full waves.
 struct ScanCfg {
-    u32 R;        // real windows of a k-mer: min(32,k) - m + 1  == ring depth
-    u32 R_init;   // real windows of the (k-1)-mer
-    u32 pitch;    // ring row pitch in u64 (odd)
-    u32 nlow;     // min(32, k)
-    u32 nlow1;    // min(32, k-1)
+    u32 nlow;     // nts of a k-mer that get_minimizer sees: min(32, k)   (F2)
+    u32 nlow1;    // same for the (k-1)-mer
     u32 nch;      // 4-nt chunks of a decycling sum: ceil((m-1)/4)
     u32 qcap;     // emit queue entries per wave
 };
@@ -341,12 +340,32 @@ __global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, cons
     out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, smem_d + 128, smem_d);
 }
 
+// Wave-wide minimum on the DPP network (no LDS round trips): quad swaps, half-row and row mirrors,
+// then the two row broadcasts leave the minimum of all 64 lanes in lane 63.  Needs a full EXEC mask.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_min_step(u32 x) {
+    const u32 y = (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xf, false);
+    return y < x ? y : x;
+}
+__device__ __forceinline__ u32 wave_min_u32(u32 x) {
+    x = dpp_min_step<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
+    x = dpp_min_step<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
+    x = dpp_min_step<0x141, 0xf>(x);  // row_half_mirror
+    x = dpp_min_step<0x140, 0xf>(x);  // row_mirror
+    x = dpp_min_step<0x142, 0xa>(x);  // row_bcast15 -> rows 1, 3
+    x = dpp_min_step<0x143, 0xc>(x);  // row_bcast31 -> rows 2, 3
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const u64 y = __shfl_xor(v, o, 64);
-        v = y < v ? y : v;
-    }
-    return v;
+    const u32 hi = (u32)(v >> 32);
+    const u32 hmin = wave_min_u32(hi);
+    const u32 lmin = wave_min_u32(hi == hmin ? (u32)v : 0xffffffffu);
+    return ((u64)hmin << 32) | lmin;
+}
+// value of a wave-uniform lane, through SGPRs
+__device__ __forceinline__ u64 read_lane_u64(u64 v, int L) {
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, L), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), L);
+    return ((u64)hi << 32) | lo;
 }
 
 // ---- long sequences: scanned as overlapping chunks, each chunk a "virtual read" ----------------
@@ -464,6 +483,26 @@ __device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first
     }
 }
 
+// what is left in the waves' queues when their reads end: one slot reservation for the whole block
+__device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, const u64* q_start,
+                                                 const u32* q_misc, const u32* q_tag, u32 qcount, u32* s_wcnt, unsigned long long* s_wbase) {
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) s_wcnt[wid] = qcount;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
+        for (u32 i = 0; i < nw; i++) total += s_wcnt[i];
+        *s_wbase = total ? atomicAdd(out.n_rec, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = *s_wbase;
+    for (u32 i = 0; i < wid; i++) base += s_wcnt[i];
+    for (u32 e = lane; e < qcount; e += 64) {
+        const u32 mi = q_misc[e];
+        emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], 0, base + e);
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
                                                 u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, int query_mode, ChunkCtl cc) {
@@ -473,9 +512,9 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const u32 n_tab = 128 + 2 * cfg.nch * 256;
     for (u32 i = tid; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
-    u64* wbase = (u64*)(smem_d + n_tab) + (size_t)wid * (64 * cfg.pitch + 2 * cfg.qcap);
-    u64* ring = wbase + lane * cfg.pitch;          // this lane's row
-    u64* q_start = wbase + 64 * cfg.pitch;         // [qcap] stream index of the super-k-mer's first nt
+    unsigned long long* s_wbase = (unsigned long long*)(smem_d + n_tab);      // block's slot base at the final flush
+    u32* s_wcnt = (u32*)(s_wbase + 1);                                         // [16] records left per wave
+    u64* q_start = (u64*)(smem_d + n_tab + 9) + (size_t)wid * (2 * cfg.qcap);  // [qcap] stream index of the super-k-mer's first nt
     u32* q_misc = (u32*)(q_start + cfg.qcap);      // [qcap] n | idx_end<<8 | rev<<16
     u32* q_tag = q_misc + cfg.qcap;                // [qcap] read index
     __syncthreads();
@@ -509,31 +548,18 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         const u32 y = __shfl_xor(max_nk, o, 64);
         max_nk = y > max_nk ? y : max_nk;
     }
-    if (max_nk == 0) return;
+    if (max_nk == 0) {  // nothing to scan in this wave; it still takes part in the block's final reservation
+        scan_final_flush(P, packed, out, q_start, q_misc, q_tag, 0, s_wcnt, s_wbase);
+        return;
+    }
     const u64 KEY0 = order_key_fast<NCH>(0, m, M, nch, s_tabs, s_coef);
+    const u64 KEY0s = read_lane_u64(KEY0, 0);  // the same value, in scalar registers
 
-    // ---- prologue: candidate state just before step -R_init, then R_init steps into the ring
-    const u32 Ri = cfg.R_init, R = cfg.R;
-    const u32 j0 = k - cfg.nlow1 - 1;  // first nt of the m-mer of step -R_init
-    u64 cf = 0, cr = 0, low64 = 0, revhist = 0;
-    if (live) {
-        if (m > 1) {
-            cf = load_nts(packed, q0 + j0, m - 1);
-            cr = rc64(cf, m - 1) << 2;
-        }
-    }
-    u32 slot = 0;  // ring slot of the next step
-    for (u32 s = 0; s < Ri; s++) {
-        u32 c = 0;
-        if (live) c = nt_at(packed, q0 + j0 + m - 1 + s);
-        cf = ((cf << 2) + c) & M;
-        cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
-        const bool revf = cr < cf;
-        ring[slot] = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
-        revhist = (revhist << 1) | (revf ? 1ull : 0ull);
-        slot = slot + 1 == R ? 0 : slot + 1;
-    }
+    // ---- prologue: the low 64 bits of the (k-1)-mer; its last m-mer seeds the rolling candidates
+    u64 cf = 0, cr = 0, low64 = 0;
     if (live) low64 = load_nts(packed, q0 + (k - 1) - cfg.nlow1, cfg.nlow1);
+    cf = low64 & M;
+    cr = rc64(cf, m);
 
     // ---- minimizer of the (k-1)-mer (Kmers.cpp:533): every lane at once, windows in lockstep
     u64 mini_hash;
@@ -547,11 +573,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         for (u32 i = 0; i <= Km; i++) {
             u64 key;
             bool rv;
-            if (i + m <= cfg.nlow1) {  // inside the low 64 bits: the key of step -1-i
-                const u32 tsl = slot + R - 1 - i;  // < 2R
-                key = ring[tsl >= R ? tsl - R : tsl];
-                rv = (revhist >> i) & 1;
-            } else if (i < cfg.nlow1) {  // zero-padded window (F2)
+            if (i < cfg.nlow1) {  // inside the low 64 bits; windows that stick out of them are zero-padded (F2)
                 const u64 fwd = (low64 >> (2 * i)) & M;
                 const u64 rcv = rc64(fwd, m);
                 rv = rcv < fwd;
@@ -605,10 +627,6 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         low64 = (low64 << 2) | c;
         const bool revf = cr < cf;
         const u64 h = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
-        revhist = (revhist << 1) | (revf ? 1ull : 0ull);
-        ring[slot] = h;
-        const u32 cur_slot = slot;
-        slot = slot + 1 == R ? 0 : slot + 1;
         mini_pos++;
         const bool expired = act && mini_pos > w;                  // Kmers.cpp:551
         const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
@@ -630,55 +648,67 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             }
             qcount += (u32)__popcll(bal);
         }
-        // re-scans, one lane's k-mer at a time, one window per lane
+        // re-scans (get_minimizer on the low 64 bits, Kmers.cpp:367-408): two lanes' k-mers per round, one
+        // window per lane of a half-wave.  Window i of a k-mer is (low64 >> 2i) & M -- zero-padded where it
+        // sticks out of the low 64 bits (F2); windows 32.. of a k > 32 are the all-A m-mer (KEY0), folded in
+        // below without lanes.
         unsigned long long need = __ballot(expired && !dead);
         while (need) {
-            const int L = __ffsll((long long)need) - 1;
+            const int LA = __ffsll((long long)need) - 1;
             need &= need - 1;
-            const u64 lowL = __shfl(low64, L, 64);
-            const u64 rhL = __shfl(revhist, L, 64);
-            u64 key = ~0ull;
-            bool rv = false;
-            if (lane <= Km) {
-                if (lane + m <= cfg.nlow) {
-                    const u32 tsl = cur_slot + R - lane;  // < 2R
-                    key = wbase[(u32)L * cfg.pitch + (tsl >= R ? tsl - R : tsl)];
-                    rv = (rhL >> lane) & 1;
-                } else if (lane >= cfg.nlow) {
-                    key = KEY0;
-                }
+            const bool two = need != 0;
+            int LB = LA;
+            if (two) {
+                LB = __ffsll((long long)need) - 1;
+                need &= need - 1;
             }
-            {
-                // zero-padded windows: computed by their lanes (all lanes run the code, few keep the result)
-                const bool fake = lane <= Km && lane + m > cfg.nlow && lane < cfg.nlow;
-                if (__any(fake)) {
-                    const u64 fwd = (lowL >> (2 * (lane & 31))) & M;
-                    const u64 rcv = rc64(fwd, m);
-                    const bool rv2 = rcv < fwd;
-                    const u64 k2 = order_key_fast<NCH>(rv2 ? rcv : fwd, m, M, nch, s_tabs, s_coef);
-                    if (fake) {
-                        key = k2;
-                        rv = rv2;
+            const u64 lowA = read_lane_u64(low64, LA), lowB = read_lane_u64(low64, LB);
+            const u32 wl = lane & 31;
+            const u64 lowL = lane < 32 ? lowA : lowB;
+            const u64 fwd = (lowL >> (2 * wl)) & M;
+            const u64 rcv = rc64(fwd, m);
+            const bool rv = rcv < fwd;
+            u64 key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+            if (wl > Km || wl >= cfg.nlow) key = ~0ull;
+            u64 hm = key;  // minimum of this lane's half
+            for (int o = 16; o > 0; o >>= 1) {
+                const u64 y = __shfl_xor(hm, o, 64);
+                hm = y < hm ? y : hm;
+            }
+            const unsigned long long tie = __ballot(key == hm);
+            const unsigned long long rvb = __ballot(rv);
+            for (int half = 0; half < (two ? 2 : 1); half++) {  // wave-uniform, scalar work
+                const int L = half ? LB : LA;
+                const u32 t = (u32)(tie >> (32 * half)), rb = (u32)(rvb >> (32 * half));
+                u64 hmin = read_lane_u64(hm, 32 * half);
+                u32 first = (u32)__ffs((int)t) - 1, last = 31u - (u32)__clz((int)t);
+                bool rf = (rb >> first) & 1, rl = (rb >> last) & 1;
+                if (Km >= 32) {  // windows 32..Km: the all-A m-mer
+                    if (KEY0s < hmin) {
+                        hmin = KEY0s;
+                        first = 32;
+                        last = Km;
+                        rf = rl = false;
+                    } else if (KEY0s == hmin) {
+                        last = Km;
+                        rl = false;
                     }
                 }
-            }
-            const u64 hmin = wave_min_u64(key);
-            const unsigned long long tie = __ballot(key == hmin);
-            const unsigned long long rvb = __ballot(rv);
-            const u32 first = (u32)__ffsll((long long)tie) - 1, last = 63u - (u32)__clzll((long long)tie);
-            u32 pos;
-            bool rev, need_canon;
-            resolve_ties(first, last, (rvb >> first) & 1, (rvb >> last) & 1, Km, false, false, &pos, &rev, &need_canon);
-            if (need_canon) {  // wave-uniform
-                const u64 qL = __shfl(q0, L, 64) + p;
-                const u64 hi = k > 32 ? load_nts(packed, qL, k - 32) : 0;
-                const u64 lo = k >= 32 ? lowL : (lowL & ((1ull << (2 * k)) - 1));
-                if (!canonized_as_executed(mk128(lo, hi), k)) rev = false;
-            }
-            if ((int)lane == L) {
-                mini_hash = hmin;
-                mini_pos = pos;
-                reversed = rev;
+                u32 pos;
+                bool rev, need_canon;
+                resolve_ties(first, last, rf, rl, Km, false, false, &pos, &rev, &need_canon);
+                if (need_canon) {  // wave-uniform
+                    const u64 lowX = half ? lowB : lowA;
+                    const u64 qL = read_lane_u64(q0, L) + p;
+                    const u64 hi = k > 32 ? load_nts(packed, qL, k - 32) : 0;
+                    const u64 lo = k >= 32 ? lowX : (lowX & ((1ull << (2 * k)) - 1));
+                    if (!canonized_as_executed(mk128(lo, hi), k)) rev = false;
+                }
+                if ((int)lane == L) {
+                    mini_hash = hmin;
+                    mini_pos = pos;
+                    reversed = rev;
+                }
             }
         }
         if (newmin) {  // Kmers.cpp:572-576
@@ -696,11 +726,15 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             last_idx = idx;
             n++;
         }
-        // turn queued super-k-mers into records with full waves
+        // turn queued super-k-mers into records with full waves.  All waves append to one record counter, and
+        // same-address atomics serialise device-wide (~15 ns each): one reservation per flush, not per record
         if (qcount + 64 > cfg.qcap) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)qcount);
+            base = read_lane_u64(base, 0);
             for (u32 e = lane; e < qcount; e += 64) {
                 const u32 mi = q_misc[e];
-                emit_record(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e]);
+                emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], 0, base + e);
             }
             qcount = 0;
         }
@@ -719,10 +753,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         }
         qcount += (u32)__popcll(bal);
     }
-    for (u32 e = lane; e < qcount; e += 64) {
-        const u32 mi = q_misc[e];
-        emit_record(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e]);
-    }
+    scan_final_flush(P, packed, out, q_start, q_misc, q_tag, qcount, s_wcnt, s_wbase);
 }
 
 // ===========================================================================
@@ -801,17 +832,40 @@ __global__ void __launch_bounds__(256) k_psum_apply(const unsigned long long* __
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) off[n] = run;  // total
 }
 
-// list of partitions with records; one wave-aggregated atomic per wave
-__global__ void __launch_bounds__(256) k_touched(const unsigned long long* __restrict__ hist, u64 n, u32* __restrict__ list, u32* __restrict__ n_list) {
-    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool hit = p < n && (u32)hist[p] != 0;
-    const unsigned long long bal = __ballot(hit);
-    if (!bal) return;
-    const u32 lane = threadIdx.x & 63;
-    u32 base = 0;
-    if (lane == (u32)__ffsll((long long)bal) - 1) base = atomicAdd(n_list, (u32)__popcll(bal));
-    base = __shfl(base, __ffsll((long long)bal) - 1, 64);
-    if (hit) list[base + __popcll(bal & ((1ull << lane) - 1))] = (u32)p;
+// list of partitions with records, ascending inside a block.  One list-cursor atomic per block of 8192
+// partitions: every same-address atomic costs ~15 ns device-wide, whoever issues it.
+#define TOUCHED_ITEMS 8
+__global__ void __launch_bounds__(1024) k_touched(const unsigned long long* __restrict__ hist, u64 n, u32* __restrict__ list, u32* __restrict__ n_list) {
+    __shared__ u32 s_wsum[16];
+    __shared__ u32 s_base;
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const u64 p0 = ((u64)blockIdx.x * 1024 + threadIdx.x) * TOUCHED_ITEMS;
+    u32 mask = 0;
+#pragma unroll
+    for (u32 j = 0; j < TOUCHED_ITEMS; j++)
+        if (p0 + j < n && (u32)hist[p0 + j] != 0) mask |= 1u << j;
+    const u32 cnt = (u32)__popc(mask);
+    u32 incl = cnt;  // inclusive scan over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += y;
+    }
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+        for (u32 i = 0; i < 16; i++) {
+            const u32 c = s_wsum[i];
+            s_wsum[i] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(n_list, tot) : 0u;
+    }
+    __syncthreads();
+    u32 at = s_base + s_wsum[wid] + incl - cnt;
+#pragma unroll
+    for (u32 j = 0; j < TOUCHED_ITEMS; j++)
+        if (mask >> j & 1) list[at++] = (u32)(p0 + j);
 }
 
 // Per touched partition: a 32-byte work descriptor for k_insert (so that its
@@ -831,9 +885,8 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
                                               const u32* __restrict__ list, u32 n_list, const DirEnt* __restrict__ dir,
                                               PartDesc* __restrict__ desc, unsigned long long* out) {
     __shared__ unsigned long long s_sum[4];
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long need = 0;
-    if (i < n_list) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {  // grid-stride: few blocks, few atomics
         const u32 p = list[i];
         PartDesc d;
         d.part = p;
@@ -846,7 +899,7 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
         d.off = de.off;
         desc[i] = d;
         const u32 tot = d.n_exist + d.n_inst;
-        if (tot > d.cap) need = grow_cap(tot);
+        if (tot > d.cap) need += grow_cap(tot);
     }
     for (int o = 32; o > 0; o >>= 1) need += __shfl_down(need, o, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = need;
@@ -857,55 +910,103 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
 // ===========================================================================
 // k_scatter: bucket radix -- move each record to its partition's slice.
 // owner mode (n_owners > 1 and by_owner): the bins are owners instead of partitions.
-// Owner routing has only n_owners (<= 64) bins: lanes of a wave that share an owner are
-// counted / ranked with ballots, so each wave issues ONE atomic per owner it holds
-// instead of 64 on the same address.
+// Owner routing has few bins (n_owners <= ROUTE_MAX_OWNERS), so a global atomic per record -- or even per
+// wave -- would serialise on a handful of addresses.  It is a two-pass radix step without them: every
+// block owns a contiguous range of records, counts them per owner in LDS (k_owner_hist), a small kernel
+// turns the [block][owner] counts into exclusive offsets (k_owner_offsets), and the second pass ranks
+// records with LDS cursors seeded from those offsets (k_owner_scatter).
+#define ROUTE_BLOCKS 2048u
+#define ROUTE_MAX_OWNERS 256u
 __device__ __forceinline__ u32 owner_of_record(const BriskParams& P, u64 hdr) {
     return (u32)(((u64)(hdr_bucket(hdr) >> P.shift) * P.n_owners) >> P.part_bits);
 }
-__global__ void __launch_bounds__(256) k_owner_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, unsigned long long* __restrict__ hist) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < n_rec;
-    u64 hdr = 0;
-    if (ok) hdr = rec[i * P.stride + P.nw];
-    const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+__global__ void __launch_bounds__(256) k_owner_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u64 chunk, u32* __restrict__ block_cnt,
+                                                    unsigned long long* __restrict__ hist) {
+    __shared__ u32 s_cnt[ROUTE_MAX_OWNERS];
+    __shared__ u32 s_inst[ROUTE_MAX_OWNERS];
+    for (u32 o = threadIdx.x; o < P.n_owners; o += 256) s_cnt[o] = s_inst[o] = 0;
+    __syncthreads();
+    const u64 begin = (u64)blockIdx.x * chunk, end = begin + chunk < n_rec ? begin + chunk : n_rec;
     const u32 lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(ok);
-    while (todo) {
-        const int lead = __ffsll((long long)todo) - 1;
-        const u32 o = __shfl(owner, lead, 64);
-        const unsigned long long same = __ballot(owner == o);
-        // records and k-mer instances of this owner in the wave
-        u32 inst = owner == o ? hdr_n(hdr) : 0;
-        for (int d = 32; d > 0; d >>= 1) inst += __shfl_xor(inst, d, 64);
-        if ((int)lane == lead) atomicAdd(&hist[o], (unsigned long long)__popcll(same) | ((unsigned long long)inst << 32));
-        todo &= ~same;
+    for (u64 base = begin; base < end; base += 256) {
+        const u64 i = base + threadIdx.x;
+        const bool ok = i < end;
+        u64 hdr = 0;
+        if (ok) hdr = rec[i * P.stride + P.nw];
+        const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+        unsigned long long todo = __ballot(ok);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const u32 o = (u32)__builtin_amdgcn_readlane((int)owner, lead);
+            const unsigned long long same = __ballot(owner == o);
+            u32 inst = owner == o ? hdr_n(hdr) : 0;  // k-mer instances of this owner in the wave
+            for (int d = 32; d > 0; d >>= 1) inst += __shfl_xor(inst, d, 64);
+            if ((int)lane == lead) {
+                atomicAdd(&s_cnt[o], (u32)__popcll(same));
+                atomicAdd(&s_inst[o], inst);
+            }
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (u32 o = threadIdx.x; o < P.n_owners; o += 256) {
+        block_cnt[(u64)blockIdx.x * P.n_owners + o] = s_cnt[o];
+        if (s_cnt[o]) atomicAdd(&hist[o], (unsigned long long)s_cnt[o] | ((unsigned long long)s_inst[o] << 32));
     }
 }
-__global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u32* __restrict__ cursor,
-                                                       u64* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < n_rec;
-    const u64* src = rec + i * P.stride;
-    u64 hdr = 0;
-    if (ok) hdr = src[P.nw];
-    const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
-    const u32 lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(ok);
-    u32 slot = 0;
-    while (todo) {
-        const int lead = __ffsll((long long)todo) - 1;
-        const u32 o = __shfl(owner, lead, 64);
-        const unsigned long long same = __ballot(owner == o);
-        u32 base = 0;
-        if ((int)lane == lead) base = atomicAdd(&cursor[o], (u32)__popcll(same));
-        base = __shfl(base, lead, 64);
-        if (owner == o) slot = base + (u32)__popcll(same & lanes_below(lane));
-        todo &= ~same;
+// counts -> exclusive offsets, in place; off[o] = first slot of owner o, off[n_owners] = total
+__global__ void __launch_bounds__(ROUTE_MAX_OWNERS) k_owner_offsets(u32 n_owners, u32 n_blocks, const unsigned long long* __restrict__ hist,
+                                                                   u32* __restrict__ block_cnt, u32* __restrict__ off) {
+    const u32 o = threadIdx.x;
+    if (o > n_owners) return;
+    u32 start = 0;
+    for (u32 j = 0; j < o && j < n_owners; j++) start += (u32)hist[j];
+    off[o] = start;
+    if (o == n_owners) return;
+    for (u32 b = 0; b < n_blocks; b++) {
+        const u32 c = block_cnt[(u64)b * n_owners + o];
+        block_cnt[(u64)b * n_owners + o] = start;
+        start += c;
     }
-    if (ok) {
-        u64* dst = out + (u64)slot * P.stride;
-        for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
+}
+__global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u64 chunk,
+                                                       const u32* __restrict__ block_off, u64* __restrict__ out) {
+    __shared__ u32 s_cur[ROUTE_MAX_OWNERS];
+    for (u32 o = threadIdx.x; o < P.n_owners; o += 256) s_cur[o] = block_off[(u64)blockIdx.x * P.n_owners + o];
+    __syncthreads();
+    const u64 begin = (u64)blockIdx.x * chunk, end = begin + chunk < n_rec ? begin + chunk : n_rec;
+    const u32 lane = threadIdx.x & 63;
+    for (u64 base = begin; base < end; base += 256) {
+        const u64 i = base + threadIdx.x;
+        const bool ok = i < end;
+        const u64* src = rec + i * P.stride;
+        u64 hdr = 0;
+        if (ok) hdr = src[P.nw];
+        const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+        unsigned long long todo = __ballot(ok);
+        u32 slot = 0;
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const u32 o = (u32)__builtin_amdgcn_readlane((int)owner, lead);
+            const unsigned long long same = __ballot(owner == o);
+            u32 b0 = 0;
+            if ((int)lane == lead) b0 = atomicAdd(&s_cur[o], (u32)__popcll(same));
+            b0 = (u32)__builtin_amdgcn_readlane((int)b0, lead);
+            if (owner == o) slot = b0 + (u32)__popcll(same & lanes_below(lane));
+            todo &= ~same;
+        }
+        if (ok) {
+            u64* dst = out + (u64)slot * P.stride;
+            if (P.stride == 4) {
+                const uint4* s4 = reinterpret_cast<const uint4*>(src);
+                uint4* d4 = reinterpret_cast<uint4*>(dst);
+                const uint4 a = s4[0], b = s4[1];
+                d4[0] = a;
+                d4[1] = b;
+            } else {
+                for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
+            }
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_part_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, unsigned long long* __restrict__ hist) {
@@ -957,7 +1058,12 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
 // ARENA_CHUNK entries.  nb_kmers / nb_buckets are reductions done at stats() time:
 // the kernel has no same-address global atomics on its data path.
 #define ARENA_CHUNK 32768u
+#ifndef INSERT_SLOTS
 #define INSERT_SLOTS 2560u   // persistent waves == private allocator slots (256 CUs x 10)
+#endif
+#ifndef WI_WAVES_PER_EU
+#define WI_WAVES_PER_EU 1
+#endif
 struct IndexDev {
     u64* keys;                   // 2 u64 per entry
     uint8_t* counts;
@@ -1031,7 +1137,7 @@ __device__ __forceinline__ u128x record_kmer_lds(const BriskParams& P, const u64
     return and128(r, mask128(2 * P.kb));
 }
 
-#define WI_BATCH 32u   // partitions a wave takes per work-counter atomic
+#define WI_BATCH 64u   // partitions a wave takes per work-counter atomic (same-address atomics serialise device-wide)
 
 // WI_NI-instances-per-lane body of the expand + de-duplicate phases (NI = 4 when the
 // chunk has <= 256 instances, else 8: all NI instances of a lane are in flight together)
@@ -1099,7 +1205,7 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
     }
 }
 
-__global__ void __launch_bounds__(64) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
                                                u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
     __shared__ u64 s_key[2 * WI_MAX_INST];
     __shared__ u64 s_rec[WI_MAX_REC * 5];

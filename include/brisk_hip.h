@@ -82,7 +82,7 @@ typedef struct brisk_hip_options {
     void *stream;               /* hipStream_t to run on, NULL: the library creates one */
     uint32_t part_bits;         /* log2(#partitions); 0: default min(2b, 24) */
     uint32_t owner_rank;        /* this process' rank among n_owners bucket-range owners */
-    uint32_t n_owners;          /* 0 or 1: this index owns every bucket */
+    uint32_t n_owners;          /* 0 or 1: this index owns every bucket; at most 256 (else EUNSUPPORTED) */
     uint64_t arena_entries;     /* initial entry capacity of the k-mer arena; 0: grow on demand */
     uint64_t max_batch_reads;   /* reads per internal scan batch; 0: default */
     uint32_t entry_ids;         /* 1: entry-id mode (per-call facade API): every entry gets a stable dense id in
