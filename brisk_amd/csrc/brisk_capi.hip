@@ -203,40 +203,49 @@ int vm_grow(brisk_hip_index* h, VmBuf& b, size_t bytes) {
         b.handles.push_back(hd);
         b.sizes.push_back(add);
         b.mapped += add;
+        static const bool dbg = getenv("BRISK_DEBUG_VMM") != nullptr;
+        if (dbg) fprintf(stderr, "[brisk_hip] vmm: base %p reserved %zu MiB: mapped +%zu MiB at %p -> %zu MiB\n", (void*)b.base, b.reserved >> 20, add >> 20,
+                         (void*)(b.base + b.mapped - add), b.mapped >> 20);
     }
     return BRISK_HIP_OK;
 }
-void vm_free(VmBuf& b) {
+void vm_free(VmBuf& b) {  // a reservation nothing was ever mapped into may go back to the runtime; anything else is retired (below)
+    if (b.base && b.handles.empty()) hipMemAddressFree(b.base, b.reserved);
     size_t off = 0;
     for (size_t i = 0; i < b.handles.size(); i++) {
         hipMemUnmap(b.base + off, b.sizes[i]);
         hipMemRelease(b.handles[i]);
         off += b.sizes[i];
     }
-    if (b.base) hipMemAddressFree(b.base, b.reserved);
     b = VmBuf{};
 }
 
-// Arenas of destroyed indexes are kept (one per process) with their first mapped pieces and handed to
-// the next index on the same device: creating and destroying indexes in a loop then neither pays for
-// reserve/map/unmap each time nor re-maps fresh physical memory at a just-released virtual address.
+// A virtual address that has been unmapped must never be mapped again in this process: on this stack
+// (ROCm 7.2, gfx950) a kernel touching memory freshly mapped at a previously unmapped address now and
+// then takes a memory access fault (seen with hipMemUnmap + hipMemMap at the same offset, and with
+// hipMemAddressFree + hipMemAddressReserve handing the same range out again).  So:
+//  * arenas of destroyed indexes go to a small pool WITH their mappings and are handed to the next
+//    index on the same device (also saves reserve/map/unmap per index);
+//  * an arena that is not pooled is retired: its physical memory is released, its virtual range stays
+//    reserved for the life of the process (address space only) so that nothing is mapped there again.
 struct VmSet {
     int device = -1;
     VmBuf keys, counts, ids;
+    size_t mapped() const { return keys.mapped + counts.mapped + ids.mapped; }
 };
 std::mutex g_pool_mu;
 std::vector<VmSet> g_pool;
-constexpr size_t kPoolKeepEntries = (size_t)1 << 30;  // entries a pooled arena keeps mapped (16 GiB of keys)
+constexpr size_t kPoolMaxArenas = 4;
+constexpr size_t kPoolMaxBytes = (size_t)40 << 30;  // physical memory the pool may hold
 
-void vm_trim(VmBuf& b, size_t keep_bytes) {  // unmap tail pieces beyond keep_bytes (the first piece always stays)
-    while (b.handles.size() > 1 && b.mapped - b.sizes.back() >= keep_bytes) {
-        const size_t sz = b.sizes.back();
-        hipMemUnmap(b.base + b.mapped - sz, sz);
-        hipMemRelease(b.handles.back());
-        b.handles.pop_back();
-        b.sizes.pop_back();
-        b.mapped -= sz;
+void vm_retire(VmBuf& b) {  // give the physical memory back, keep the address range out of circulation
+    size_t off = 0;
+    for (size_t i = 0; i < b.handles.size(); i++) {
+        hipMemUnmap(b.base + off, b.sizes[i]);
+        hipMemRelease(b.handles[i]);
+        off += b.sizes[i];
     }
+    b = VmBuf{};
 }
 bool pool_take(int device, bool want_ids, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -246,22 +255,22 @@ bool pool_take(int device, bool want_ids, VmBuf& keys, VmBuf& counts, VmBuf& ids
         counts = g_pool[i].counts;
         ids = g_pool[i].ids;
         g_pool.erase(g_pool.begin() + i);
-        if (!want_ids) vm_free(ids);
+        if (!want_ids) vm_retire(ids);
         return true;
     }
     return false;
 }
 void pool_give(int device, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (!g_pool.empty() || !keys.base || !counts.base) {
-        vm_free(keys);
-        vm_free(counts);
-        vm_free(ids);
+    size_t held = 0;
+    for (const VmSet& s : g_pool) held += s.mapped();
+    const size_t mine = keys.mapped + counts.mapped + ids.mapped;
+    if (!keys.base || !counts.base || g_pool.size() >= kPoolMaxArenas || held + mine > kPoolMaxBytes) {
+        vm_retire(keys);
+        vm_retire(counts);
+        vm_retire(ids);
         return;
     }
-    vm_trim(keys, kPoolKeepEntries * 16);
-    vm_trim(counts, kPoolKeepEntries);
-    vm_trim(ids, kPoolKeepEntries * 4);
     VmSet s;
     s.device = device;
     s.keys = keys;

@@ -1058,11 +1058,16 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
 // ARENA_CHUNK entries.  nb_kmers / nb_buckets are reductions done at stats() time:
 // the kernel has no same-address global atomics on its data path.
 #define ARENA_CHUNK 32768u
+// k_insert is bound by each wave's own serial instruction stream (LDS round trips, short dependent
+// chains), so throughput follows the number of resident waves: chunks of 256 instances keep LDS at
+// 10 KB and registers at 128 per wave => 4 waves per SIMD (512-instance chunks: 16 KB, 201 registers,
+// 2 waves per SIMD, 61 ms instead of 50 ms on the 50M-read job; 128-instance chunks spill and split
+// too many partitions: 84 ms).
 #ifndef INSERT_SLOTS
-#define INSERT_SLOTS 2560u   // persistent waves == private allocator slots (256 CUs x 10)
+#define INSERT_SLOTS 4096u   // persistent waves == private allocator slots (256 CUs x 4 SIMDs x 4 waves)
 #endif
 #ifndef WI_WAVES_PER_EU
-#define WI_WAVES_PER_EU 1
+#define WI_WAVES_PER_EU 4
 #endif
 struct IndexDev {
     u64* keys;                   // 2 u64 per entry
@@ -1082,8 +1087,10 @@ struct IndexDev {
 // independent stream of partitions, so a CU keeps ~10 of them in flight and their
 // LDS / HBM latencies overlap.  Sized for partitions of a few hundred k-mer
 // instances (part_bits = 24 at b = 14: 16 buckets per partition).
-#define WI_MAX_INST 512     // k-mer instances per chunk
-#define WI_TABLE 1024       // LDS table slots (load <= 0.5)
+#ifndef WI_MAX_INST
+#define WI_MAX_INST 256     // k-mer instances per chunk
+#endif
+#define WI_TABLE (2 * WI_MAX_INST)   // LDS table slots (load <= 0.5)
 #define WI_MAX_REC 64       // records per chunk: one per lane
 #define WI_CNT_SHIFT 10     // table word = [MATCHED | multiplicity (21 b) | instance (10 b)]
 #define WI_IDX_MASK 0x3ffu
@@ -1208,10 +1215,10 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
                                                u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
     __shared__ u64 s_key[2 * WI_MAX_INST];
-    __shared__ u64 s_rec[WI_MAX_REC * 5];
+    __shared__ u64 s_rec[WI_MAX_REC * 5 > WI_MAX_INST / 2 ? WI_MAX_REC * 5 : WI_MAX_INST / 2];
     __shared__ u32 s_tab[WI_TABLE];
     __shared__ u32 s_pref[WI_MAX_REC + 1];
-    __shared__ u32 s_list[WI_MAX_INST];
+    u32* s_list = (u32*)s_rec;  // [WI_MAX_INST] the new entries' table words: built after the records have been expanded
     __shared__ u32 s_rtab[2 * WI_MAX_REC];
     __shared__ u32 s_rmult[WI_MAX_REC];
     __shared__ uint8_t s_irec[WI_MAX_INST];
@@ -1408,7 +1415,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 }
                 n_exist += n_new;
                 rc += nrec;
-                if (rc < r_end) __threadfence();  // the next chunk re-reads what this one appended
+                // the next chunk re-reads what this one appended: same wave, same CU, so the stores only have to be
+                // complete (workgroup scope).  __threadfence() would write back and invalidate the XCD's whole L2.
+                if (rc < r_end) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
             for (int o = 32; o > 0; o >>= 1) {
                 bm0 |= __shfl_xor(bm0, o, 64);
@@ -1768,7 +1777,7 @@ __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const
                 out_id[qi] = nid;
                 out_new[qi] = 1;
             }
-            __threadfence();  // the next k-mer of the vector reads this partition again
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the next k-mer of the vector reads this partition again (same wave)
         }
         done = qi + 1;
     }
