@@ -340,28 +340,6 @@ __global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, cons
     out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, smem_d + 128, smem_d);
 }
 
-// Wave-wide minimum on the DPP network (no LDS round trips): quad swaps, half-row and row mirrors,
-// then the two row broadcasts leave the minimum of all 64 lanes in lane 63.  Needs a full EXEC mask.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ u32 dpp_min_step(u32 x) {
-    const u32 y = (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xf, false);
-    return y < x ? y : x;
-}
-__device__ __forceinline__ u32 wave_min_u32(u32 x) {
-    x = dpp_min_step<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
-    x = dpp_min_step<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
-    x = dpp_min_step<0x141, 0xf>(x);  // row_half_mirror
-    x = dpp_min_step<0x140, 0xf>(x);  // row_mirror
-    x = dpp_min_step<0x142, 0xa>(x);  // row_bcast15 -> rows 1, 3
-    x = dpp_min_step<0x143, 0xc>(x);  // row_bcast31 -> rows 2, 3
-    return (u32)__builtin_amdgcn_readlane((int)x, 63);
-}
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-    const u32 hi = (u32)(v >> 32);
-    const u32 hmin = wave_min_u32(hi);
-    const u32 lmin = wave_min_u32(hi == hmin ? (u32)v : 0xffffffffu);
-    return ((u64)hmin << 32) | lmin;
-}
 // value of a wave-uniform lane, through SGPRs
 __device__ __forceinline__ u64 read_lane_u64(u64 v, int L) {
     const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, L), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), L);
@@ -1323,12 +1301,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
 
                 // ---- 0/1. expand to entry keys and de-duplicate
                 if (P.nw == 3) {  // k63/m21/b14 and neighbours: compile-time record width
-                    if (ninst <= 128) expand_and_dedupe<2, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else if (ninst <= 256) expand_and_dedupe<4, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    if (ninst <= 64) expand_and_dedupe<1, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (ninst <= 128) expand_and_dedupe<2, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (ninst <= 192) expand_and_dedupe<3, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else expand_and_dedupe<WI_NI, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                 } else {
                     if (ninst <= 128) expand_and_dedupe<2, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else if (ninst <= 256) expand_and_dedupe<4, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else expand_and_dedupe<WI_NI, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                 }
                 wave_sync();
