@@ -1311,7 +1311,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 }
                 wave_sync();
 
-                // ---- 2. existing entries probe the table
+                // ---- 2. existing entries probe the table.  After the first chunk they include what this wave
+                // appended itself: same wave, same CU, so those stores only have to be complete (workgroup
+                // scope; __threadfence() would write back and invalidate the XCD's whole L2), and waiting
+                // for them here rather than at the end of the last chunk hides them behind phases 0 and 1.
+                if (rc != d.r_begin) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 for (u32 e = lane; e < n_exist; e += 64) {
                     const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
                     u32 h = hash_key32(key) & (tsize - 1);
@@ -1393,9 +1397,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 }
                 n_exist += n_new;
                 rc += nrec;
-                // the next chunk re-reads what this one appended: same wave, same CU, so the stores only have to be
-                // complete (workgroup scope).  __threadfence() would write back and invalidate the XCD's whole L2.
-                if (rc < r_end) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
             }
             for (int o = 32; o > 0; o >>= 1) {
                 bm0 |= __shfl_xor(bm0, o, 64);
