@@ -573,13 +573,22 @@ int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_sta
     return BRISK_HIP_OK;
 }
 
+// records (with a tag each) -> d_sums[tag] += sum of the counts of the record's k-mers that are present.
+// d_hist holds the records' per-partition histogram; d_sums must be zeroed by the caller.
+int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums);
+
 int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, unsigned long long* d_sums) {
     // d_sums[n_reads] must be zeroed by the caller
-    const BriskParams& P = h->P;
     u64 n_rec = 0;
     int rc;
     if ((rc = scan_to_staging(h, d_packed, d_starts, n_reads, true, true, &n_rec))) return rc;
     if (n_rec == 0) return BRISK_HIP_OK;
+    return query_records_impl(h, (const u64*)h->staging.p, (const u32*)h->tags_a.p, n_rec, d_sums);
+}
+
+int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums) {
+    const BriskParams& P = h->P;
+    int rc;
     if ((rc = prefix_partitions(h, h->n_parts))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
     hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 1024 * TOUCHED_ITEMS)), dim3(1024), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
@@ -587,8 +596,8 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     if (int lrc = launch_check(h, "k_touched")) return lrc;
     if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
     if ((rc = ensure(h, h->tags_b, n_rec * 4))) return rc;
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, (const u64*)h->staging.p, n_rec, h->d_cur32,
-                       (u64*)h->parted.p, 0, (const u32*)h->tags_a.p, (u32*)h->tags_b.p, h->ix.err);
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_cur32,
+                       (u64*)h->parted.p, 0, d_tags, (u32*)h->tags_b.p, h->ix.err);
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const u32 n_touched = (u32)h->h_small[2];
@@ -1120,7 +1129,18 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     return rc;
 }
 
+static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint32_t* d_tags, uint64_t n_records, uint64_t* d_out, uint32_t* d_tags_out,
+                      uint64_t* counts);
 BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records, uint64_t* d_out, uint64_t* counts) {
+    return route_impl(h, d_records, nullptr, n_records, d_out, nullptr, counts);
+}
+BRISK_API int brisk_hip_route_tagged(brisk_hip_index* h, const uint64_t* d_records, const uint32_t* d_tags, uint64_t n_records, uint64_t* d_out,
+                                     uint32_t* d_tags_out, uint64_t* counts) {
+    if (n_records && (!d_tags || !d_tags_out)) return BRISK_HIP_EINVAL;
+    return route_impl(h, d_records, d_tags, n_records, d_out, d_tags_out, counts);
+}
+static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint32_t* d_tags, uint64_t n_records, uint64_t* d_out, uint32_t* d_tags_out,
+                      uint64_t* counts) {
     if (!h || !counts || (n_records && (!d_records || !d_out))) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     const u32 no = h->P.n_owners;
@@ -1143,7 +1163,7 @@ BRISK_API int brisk_hip_route_records(brisk_hip_index* h, const uint64_t* d_reco
     }
     {
         ProfScope ps(h, S_SCATTER);
-        hipLaunchKernelGGL(k_owner_scatter, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_out);
+        hipLaunchKernelGGL(k_owner_scatter, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_out, d_tags, d_tags_out);
         if ((rc = launch_check(h, "k_owner_scatter"))) return rc;
     }
     std::vector<u32> off(no + 1);
@@ -1158,6 +1178,36 @@ BRISK_API int brisk_hip_insert_records(brisk_hip_index* h, const uint64_t* d_rec
     HIPCHK(h, hipSetDevice(h->device));
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     return insert_records_impl(h, d_records, n_records, false);
+}
+
+BRISK_API int brisk_hip_scan_query(brisk_hip_index* h, const uint32_t* d_packed, const uint64_t* d_starts, uint64_t n_reads, uint64_t* d_records,
+                                   uint32_t* d_tags, uint64_t cap_records, uint64_t* n_records) {
+    if (!h || !n_records || (n_reads && (!d_packed || !d_starts)) || (cap_records && (!d_records || !d_tags))) return BRISK_HIP_EINVAL;
+    if (n_reads >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 reads in one query batch");
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_records = 0;
+    if (!n_reads) return BRISK_HIP_OK;
+    u64 n = 0;
+    int rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, true, d_tags, &n);
+    *n_records = n;
+    return rc;
+}
+
+BRISK_API int brisk_hip_query_records(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records, uint64_t* d_sums) {
+    if (!h || (n_records && (!d_records || !d_sums))) return BRISK_HIP_EINVAL;
+    if (n_records >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!n_records) return BRISK_HIP_OK;
+    int rc;
+    if ((rc = ensure(h, h->tags_a, n_records * 4))) return rc;
+    HIPCHK(h, hipMemsetAsync(d_sums, 0, n_records * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+    hipLaunchKernelGGL(k_iota, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, (u32*)h->tags_a.p, n_records);
+    hipLaunchKernelGGL(k_part_hist, dim3(nblocks(n_records, 256)), dim3(256), 0, h->stream, h->P, d_records, n_records, h->d_hist);
+    if ((rc = launch_check(h, "k_part_hist"))) return rc;
+    if ((rc = query_records_impl(h, d_records, (const u32*)h->tags_a.p, n_records, (unsigned long long*)d_sums))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return check_device_flags(h);
 }
 
 // ---- the per-call API under the C++ facade ----------------------------------------

@@ -948,7 +948,8 @@ __global__ void __launch_bounds__(ROUTE_MAX_OWNERS) k_owner_offsets(u32 n_owners
     }
 }
 __global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u64 chunk,
-                                                       const u32* __restrict__ block_off, u64* __restrict__ out) {
+                                                       const u32* __restrict__ block_off, u64* __restrict__ out,
+                                                       const u32* __restrict__ tag_in, u32* __restrict__ tag_out) {
     __shared__ u32 s_cur[ROUTE_MAX_OWNERS];
     for (u32 o = threadIdx.x; o < P.n_owners; o += 256) s_cur[o] = block_off[(u64)blockIdx.x * P.n_owners + o];
     __syncthreads();
@@ -984,8 +985,13 @@ __global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64*
             } else {
                 for (u32 j = 0; j < P.stride; j++) dst[j] = src[j];
             }
+            if (tag_in) tag_out[slot] = tag_in[i];
         }
     }
+}
+__global__ void __launch_bounds__(256) k_iota(u32* __restrict__ out, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (u32)i;
 }
 __global__ void __launch_bounds__(256) k_part_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, unsigned long long* __restrict__ hist) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -56,6 +56,19 @@ def exchange_records(send: torch.Tensor, send_counts, words: int, group=None,
     return inbox, recv_counts
 
 
+def return_sums(sums: torch.Tensor, recv_counts, send_counts, tags: torch.Tensor, n_reads: int, group=None) -> torch.Tensor:
+    """Return trip of a sharded get.  `sums` (int64, one per record this rank answered, in the order the
+    records arrived: grouped by source rank) goes back to the ranks the records came from; what comes
+    back is in the order this rank sent its own records, so `tags` (read index per sent record) folds it
+    into per-read sums."""
+    back, _ = exchange_records(sums, recv_counts, 1, group, None)
+    n_out = int(sum(int(c) for c in send_counts))
+    per_read = torch.zeros(n_reads, dtype=torch.int64, device=sums.device)
+    if n_out:
+        per_read.index_add_(0, tags[:n_out].to(torch.int64), back[:n_out])
+    return per_read
+
+
 class ShardedCounter:
     """A rank's share of a k-mer counting job: owns the buckets of its partition range."""
 
@@ -94,3 +107,34 @@ class ShardedCounter:
             self._inbox, recv_counts = exchange_records(self._out, counts, W, self.group, self._inbox)
             self.stream.synchronize()
             ix.insert_records(self._inbox.data_ptr(), sum(recv_counts))
+
+    def get_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> torch.Tensor:
+        """Per-read sum of the counts of the read's k-mers (query_sequence, apps/counter.cpp:281-310), with the
+        buckets spread over the ranks: scan in query mode here, route the records (and the index of the
+        read each came from) to the owners, the owners answer per record, the answers travel back."""
+        ix, W = self.ix, self.W
+        import brisk_amd
+        with torch.cuda.stream(self.stream):
+            cap = ix.scan_bound(d_starts.data_ptr(), n_reads)
+            rec = torch.empty(max(cap, 1) * W, dtype=torch.int64, device=self.dev)
+            tags = torch.empty(max(cap, 1), dtype=torch.int32, device=self.dev)
+            self.stream.synchronize()
+            n_rec = ix.scan_query(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, rec.data_ptr(), tags.data_ptr(), cap)
+            out = torch.empty(max(n_rec, 1) * W, dtype=torch.int64, device=self.dev)
+            tags_out = torch.empty(max(n_rec, 1), dtype=torch.int32, device=self.dev)
+            self.stream.synchronize()
+            counts = ix.route_tagged(rec.data_ptr(), tags.data_ptr(), n_rec, out.data_ptr(), tags_out.data_ptr())
+            if self.world == 1:
+                inbox, recv_counts = out, [n_rec]
+            else:
+                inbox, recv_counts = exchange_records(out, counts, W, self.group, None)
+            n_in = sum(recv_counts)
+            sums = torch.zeros(max(n_in, 1), dtype=torch.int64, device=self.dev)
+            self.stream.synchronize()
+            ix.query_records(inbox.data_ptr(), n_in, sums.data_ptr())
+            if self.world == 1:
+                per_read = torch.zeros(n_reads, dtype=torch.int64, device=self.dev)
+                if n_rec:
+                    per_read.index_add_(0, tags_out[:n_rec].to(torch.int64), sums[:n_rec])
+                return per_read
+            return return_sums(sums[:max(n_in, 1)], recv_counts, counts, tags_out, n_reads, self.group)

@@ -101,7 +101,7 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_insert_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
+    "brisk_hip_insert_records", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
@@ -137,6 +137,9 @@ def load() -> C.CDLL:
     L.brisk_hip_scan_bound.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.brisk_hip_route_records.argtypes = [vp, vp, u64, vp, _u64p]
     L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
+    L.brisk_hip_scan_query.argtypes = [vp, vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
+    L.brisk_hip_route_tagged.argtypes = [vp, vp, vp, u64, vp, vp, _u64p]
+    L.brisk_hip_query_records.argtypes = [vp, vp, u64, vp]
     L.brisk_hip_pack_ascii.argtypes = [vp, vp, u64, vp]
     L.brisk_hip_synth_reads.argtypes = [vp, u64, u64, u64, u32, u64, u64, vp, vp]
     _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
@@ -314,6 +317,24 @@ class BriskHip:
 
     def insert_records(self, d_records: int, n: int):
         self._chk(self.L.brisk_hip_insert_records(self.h, d_records, n))
+
+    def scan_query(self, d_packed: int, d_starts: int, n_reads: int, d_records: int, d_tags: int, cap: int) -> int:
+        """query-mode scan: records + the index of the read each came from (u32)"""
+        out = C.c_uint64()
+        rc = self.L.brisk_hip_scan_query(self.h, d_packed, d_starts, n_reads, d_records, d_tags, cap, C.byref(out))
+        if rc == ECAPACITY:
+            raise BriskHipError(rc, f"scan needs {out.value} records, cap {cap}")
+        self._chk(rc)
+        return out.value
+
+    def route_tagged(self, d_records: int, d_tags: int, n: int, d_out: int, d_tags_out: int) -> np.ndarray:
+        counts = np.zeros(max(self.layout["n_owners"], 1), np.uint64)
+        self._chk(self.L.brisk_hip_route_tagged(self.h, d_records, d_tags, n, d_out, d_tags_out, counts))
+        return counts
+
+    def query_records(self, d_records: int, n: int, d_sums: int):
+        """d_sums[i] (u64) = sum of the counts of record i's k-mers present in this index"""
+        self._chk(self.L.brisk_hip_query_records(self.h, d_records, n, d_sums))
 
     def pack_ascii(self, d_bases: int, n_bases: int, d_packed: int):
         self._chk(self.L.brisk_hip_pack_ascii(self.h, d_bases, n_bases, d_packed))

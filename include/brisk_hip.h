@@ -41,6 +41,9 @@
  *                               apps/counter.cpp:242-261) so that records can be
  *                               exchanged between GPUs (no reference counterpart:
  *                               the reference is single-process)
+ *   brisk_hip_scan_query / brisk_hip_route_tagged / brisk_hip_query_records
+ *                               the query path (apps/counter.cpp:281-310, brisk/Brisk.hpp:102-118) cut at the
+ *                               same boundary, for a get across bucket-range shards
  *   brisk_hip_scan_sequence     SuperKmerEnumerator ctor + next() until empty (brisk/Kmers.cpp:509-603)
  *   brisk_hip_upsert_kmers      Brisk::insert_superkmer (brisk/Brisk.hpp:123-147) minus the DATA pointers,
  *                               which the facade forms from the returned ids
@@ -171,6 +174,18 @@ int brisk_hip_route_records(brisk_hip_index *h, const uint64_t *d_records, uint6
                             uint64_t *d_out, uint64_t *counts);
 /* insert records whose buckets this index owns */
 int brisk_hip_insert_records(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records);
+/* The query path cut at the same boundary.  scan_query = the scan as query_sequence runs it (a read's
+ * enumeration stops at the first super-k-mer after the first whose returned minimizer is 0,
+ * apps/counter.cpp:304-306); d_tags[i] = index of the read record i came from.  route_tagged = route_records
+ * carrying the tags along.  query_records: d_sums[i] = sum of the counts of record i's k-mers present in
+ * THIS index (records whose buckets it owns), what Brisk::get_superkmer + the caller's loop add up
+ * (brisk/Brisk.hpp:102-118, apps/counter.cpp:296-303).  A sharded get is scan_query -> route_tagged ->
+ * all-to-all -> query_records on the owner -> all-to-all back -> per_read[tag] += sum. */
+int brisk_hip_scan_query(brisk_hip_index *h, const uint32_t *d_packed, const uint64_t *d_starts, uint64_t n_reads,
+                         uint64_t *d_records, uint32_t *d_tags, uint64_t cap_records, uint64_t *n_records);
+int brisk_hip_route_tagged(brisk_hip_index *h, const uint64_t *d_records, const uint32_t *d_tags, uint64_t n_records,
+                           uint64_t *d_out, uint32_t *d_tags_out, uint64_t *counts);
+int brisk_hip_query_records(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records, uint64_t *d_sums);
 
 /* ---- the per-call API under the C++ facade (entry-id mode) --------------------- */
 /* SuperKmerEnumerator over one clean sequence (len >= k): every vector next() would

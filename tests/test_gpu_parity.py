@@ -233,6 +233,77 @@ def test_bucket_range_sharding_two_owners(B, O):
         assert (sorted(lines), nk, nb) == want
 
 
+def test_get_across_two_owners(B, O):
+    """sharded get: scan_query -> route_tagged -> (exchange) -> query_records on the owner -> sums back ->
+    per-read sums == the oracle's query of the whole index (incl. the minimizer==0 break, poly-A reads)"""
+    import torch
+    rng = random.Random(43)
+    reads = _random_reads(rng, 500, 5000) + SPECIAL + ["A" * 200, "ACGT" * 60]
+    for k, m, b in ((63, 21, 14), (31, 11, 4)):
+        flat, offs = oracle.pack_reads(reads)
+        h = O.index_new(k, m, b)
+        O.index_insert_reads(h, flat, offs)
+        want = O.index_query_reads(h, flat, offs)
+        O.index_free(h)
+        owners = [B.BriskHip(k, m, b, owner_rank=r, n_owners=2) for r in range(2)]
+        W = owners[0].record_words
+        d_bases = torch.from_numpy(flat).cuda()
+        d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+        d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        owners[0].pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        owners[0].sync()
+        n = len(reads)
+        bound = owners[0].scan_bound(d_starts.data_ptr(), n)
+        # count: one scan, routed to the two owners
+        d_rec = torch.zeros(max(bound, 1) * W, dtype=torch.int64, device="cuda")
+        d_out = torch.zeros_like(d_rec)
+        torch.cuda.synchronize()
+        n_rec = owners[0].scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), n, d_rec.data_ptr(), bound)
+        counts = owners[0].route_records(d_rec.data_ptr(), n_rec, d_out.data_ptr())
+        o0 = int(counts[0])
+        owners[0].insert_records(d_out.data_ptr(), o0)
+        owners[1].insert_records(d_out[o0 * W:].data_ptr(), n_rec - o0)
+        # get: query-mode scan with read tags, routed, answered per record by the owner, folded per read
+        d_tags = torch.zeros(max(bound, 1), dtype=torch.int32, device="cuda")
+        d_tags_out = torch.zeros_like(d_tags)
+        torch.cuda.synchronize()
+        nq = owners[0].scan_query(d_packed.data_ptr(), d_starts.data_ptr(), n, d_rec.data_ptr(), d_tags.data_ptr(), bound)
+        counts = owners[0].route_tagged(d_rec.data_ptr(), d_tags.data_ptr(), nq, d_out.data_ptr(), d_tags_out.data_ptr())
+        q0 = int(counts[0])
+        assert int(counts.sum()) == nq
+        sums = torch.zeros(max(nq, 1), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        owners[0].query_records(d_out.data_ptr(), q0, sums.data_ptr())
+        owners[1].query_records(d_out[q0 * W:].data_ptr(), nq - q0, sums[q0:].data_ptr())
+        per_read = torch.zeros(n, dtype=torch.int64, device="cuda")
+        per_read.index_add_(0, d_tags_out[:nq].to(torch.int64), sums[:nq])
+        assert np.array_equal(per_read.cpu().numpy().astype(np.uint64), want), (k, m, b)
+        for o in owners:
+            o.close()
+    # the same calls behind ShardedCounter.get_packed (one rank owning everything)
+    from brisk_amd.exchange import ShardedCounter
+    k, m, b = 63, 21, 14
+    flat, offs = oracle.pack_reads(reads)
+    h = O.index_new(k, m, b)
+    O.index_insert_reads(h, flat, offs)
+    want = O.index_query_reads(h, flat, offs)
+    O.index_free(h)
+    stream = torch.cuda.Stream()
+    sc = ShardedCounter(k, m, b, 0, 1, 0, stream)
+    d_bases = torch.from_numpy(flat).cuda()
+    d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    sc.ix.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+    sc.ix.sync()
+    sc.count_packed(d_packed, d_starts, len(reads))
+    got = sc.get_packed(d_packed, d_starts, len(reads))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().astype(np.uint64), want)
+    sc.ix.close()
+
+
 def test_device_synth_generator_matches_oracle(B, O):
     import torch
     k, m, b = 63, 21, 14

@@ -38,6 +38,53 @@ def _expand(rec, W, k, b):
     return out
 
 
+def _records_with_tags(O, h, reads, k, m, b):
+    W = int(O.lib.bo_record_words(k, m, b)) + 1
+    rows, tags = [], []
+    for t, s in enumerate(reads):
+        c, bucket, n, idx0 = O.records(h, s, k, m, b)
+        for i in range(len(n)):
+            hdr = int(bucket[i]) | (int(n[i]) << 32) | (int(idx0[i]) << 40)
+            rows.append([int(x) for x in c[i]] + [hdr])
+            tags.append(t)
+    return np.array(rows, dtype=np.uint64).reshape(-1, W), np.array(tags, dtype=np.int64), W
+
+
+def _get_worker(rank, world, port, k, m, b, part_bits, q):
+    """sharded get on CPU: the owners' device work (insert, per-record sums) is done with python dicts
+    over the oracle's records; what is under test is the route, the two all-to-alls and return_sums"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from collections import Counter
+    from brisk_amd.exchange import exchange_records, owner_of_bucket, return_sums
+    O = oracle.Oracle()
+    reads = [bytes(r) for r in O.synth_reads(5000, 0, 400)]
+    mine = reads[rank::world]
+    h = O.index_new(k, m, b)
+    rec, tags, W = _records_with_tags(O, h, mine, k, m, b)
+    O.index_free(h)
+    owner = owner_of_bucket((rec[:, W - 1] & np.uint64(0xffffffff)).astype(np.int64), b, part_bits, world)
+    order = np.argsort(owner, kind="stable")
+    counts = np.bincount(owner, minlength=world)
+    send = torch.from_numpy(rec[order].astype(np.int64).reshape(-1))
+    tags_out = torch.from_numpy(tags[order])
+    # count: the owner's share of the index
+    inbox, recv_counts = exchange_records(send, counts, W)
+    got = inbox[: sum(recv_counts) * W].numpy().view(np.uint64).reshape(-1, W)
+    mine_counts = Counter(_expand(got, W, k, b))
+    # get: the same records travel again, the owner answers one sum per record
+    inbox, recv_counts = exchange_records(send, counts, W)
+    got = inbox[: sum(recv_counts) * W].numpy().view(np.uint64).reshape(-1, W)
+    sums = torch.tensor([sum(mine_counts[key] % 256 for key in _expand(got[i:i + 1], W, k, b)) for i in range(len(got))], dtype=torch.int64)
+    per_read = return_sums(sums, recv_counts, [int(c) for c in counts], tags_out, len(mine))
+    q.put((rank, [int(v) for v in per_read.tolist()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, k, m, b, part_bits, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -92,3 +139,28 @@ def test_two_rank_exchange_matches_oracle(O, k, m, b, part_bits):
     assert len(total) == nk
     assert sorted(c % 256 for c in total.values()) == sorted(int(l.split()[2]) for l in lines)
     assert len({key[0] for key in total}) == nb
+
+
+@pytest.mark.parametrize("k,m,b,part_bits", [(63, 21, 14, 24), (31, 11, 4, 8)])
+def test_two_rank_get_return_trip_matches_oracle(O, k, m, b, part_bits):
+    """get across bucket-range shards: records out, per-record sums back, folded per read"""
+    import oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_get_worker, args=(r, world, port, k, m, b, part_bits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    reads = [bytes(r) for r in O.synth_reads(5000, 0, 400)]
+    flat, offs = oracle.pack_reads(reads)
+    h = O.index_new(k, m, b)
+    O.index_insert_reads(h, flat, offs)
+    want = [int(v) for v in O.index_query_reads(h, flat, offs)]
+    O.index_free(h)
+    for r in range(world):
+        assert res[r] == want[r::world]
