@@ -149,7 +149,8 @@ def main():
     if N > 1:
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)
     chk = [int(v) for v in chk.cpu().tolist()]
-    verify = {"entries": chk[0], "sum_counts": chk[1], "sum_counts_expected": total_reads * max(L - k + 1, 0),
+    whole = sc.stats()  # Brisk::stats of the sharded index: sums (and one max) over the owners
+    verify = {"entries": chk[0], "nb_kmers": whole["nb_kmers"], "nb_buckets": whole["nb_buckets"], "sum_counts": chk[1], "sum_counts_expected": total_reads * max(L - k + 1, 0),
               "every_kmer_counted_once": chk[1] == total_reads * max(L - k + 1, 0),
               "digest_mod_2_64": (chk[2] + (chk[3] << 22) + (chk[4] << 44)) % (1 << 64)}
 

@@ -108,6 +108,22 @@ class ShardedCounter:
             self.stream.synchronize()
             ix.insert_records(self._inbox.data_ptr(), sum(recv_counts))
 
+    def stats(self) -> dict:
+        """Brisk::stats of the whole sharded index: buckets, super-k-mers, entries and memory add up over the
+        owners (bucket ranges are disjoint), the largest bucket is the maximum."""
+        st = self.ix.stats()
+        if self.world == 1:
+            return st
+        keys = ("nb_buckets", "nb_skmers", "nb_kmers", "memory_bytes")
+        dev = self.dev if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
+        add = torch.tensor([int(st[k]) for k in keys], dtype=torch.int64, device=dev)
+        big = torch.tensor([int(st["largest_bucket"])], dtype=torch.int64, device=dev)
+        dist.all_reduce(add, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(big, op=dist.ReduceOp.MAX, group=self.group)
+        out = {k: int(v) for k, v in zip(keys, add.cpu().tolist())}
+        out["largest_bucket"] = int(big.item())
+        return out
+
     def get_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> torch.Tensor:
         """Per-read sum of the counts of the read's k-mers (query_sequence, apps/counter.cpp:281-310), with the
         buckets spread over the ranks: scan in query mode here, route the records (and the index of the
