@@ -448,70 +448,101 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
     int rc;
     u32 n_vr = 0;
     const bool may_chunk = !plain && !query_mode && !d_tags && kmer_bound > SCAN_LONG;
-    VRead* d_vr = nullptr;
+    VRead *d_vr = nullptr, *d_rerun = nullptr;
     ChunkState *d_spec = nullptr, *d_truth = nullptr;
-    u32* d_bad = nullptr;
+    u32 *d_status = nullptr, *d_cursor = nullptr, *d_stop = nullptr;
     u64 cap_vr = 0;
+    // chunk length: long enough to amortise the warm-up, short enough to give the device lanes to fill
+    u32 chunk = 4096;
+    while (chunk > 1024 && kmer_bound / chunk < (1u << 18)) chunk >>= 1;
     if (may_chunk) {
-        cap_vr = kmer_bound / SCAN_CHUNK + kmer_bound / SCAN_LONG + 2;
-        const size_t bytes = cap_vr * sizeof(VRead) + (2 * cap_vr + 1) * sizeof(ChunkState) + (n_reads + 1) * 4;
+        cap_vr = kmer_bound / chunk + kmer_bound / SCAN_LONG + 2;
+        const u64 cap_long = kmer_bound / SCAN_LONG + 1;
+        const size_t bytes = 2 * cap_vr * sizeof(VRead) + (2 * cap_vr + 1) * sizeof(ChunkState) + 3 * cap_vr * 4 + cap_long * sizeof(LongRead);
         if ((rc = ensure(h, h->chunk_buf, bytes))) return rc;
         d_vr = (VRead*)h->chunk_buf.p;
-        d_spec = (ChunkState*)(d_vr + cap_vr);
+        d_rerun = d_vr + cap_vr;
+        d_spec = (ChunkState*)(d_rerun + cap_vr);
         d_truth = d_spec + cap_vr;
-        d_bad = (u32*)(d_truth + cap_vr + 1);
-        HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_plan_chunks, dim3(nblocks(n_reads, 256)), dim3(256), 0, h->stream, d_starts, n_reads, h->P.k, h->P.w, d_vr, (u32)cap_vr,
-                           (u32*)(h->d_small + 7));
+        d_status = (u32*)(d_truth + cap_vr + 1);
+        d_cursor = d_status + cap_vr;
+        d_stop = d_cursor + cap_vr;
+        LongRead* d_long = (LongRead*)(d_stop + cap_vr + (cap_vr & 1));
+        HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 16, h->stream));
+        hipLaunchKernelGGL(k_plan_chunks, dim3(nblocks(n_reads, 256)), dim3(256), 0, h->stream, d_starts, n_reads, h->P.k, chunk, (u32)cap_vr,
+                           (u32*)(h->d_small + 7), d_long, (u32*)(h->d_small + 6));
         if (int lrc = launch_check(h, "k_plan_chunks")) return lrc;
-        HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_small + 6, h->d_small + 6, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        const u32 n_long = (u32)h->h_small[6];
+        if (n_long) {
+            hipLaunchKernelGGL(k_fill_chunks, dim3(std::min<u32>(n_long, 65535u)), dim3(256), 0, h->stream, d_starts, (u32)h->P.k, (u32)h->P.w, chunk, d_long, n_long, d_vr);
+            if (int lrc = launch_check(h, "k_fill_chunks")) return lrc;
+        }
         n_vr = (u32)h->h_small[7];
         if (n_vr > cap_vr) return fail(h, BRISK_HIP_EHIP, "chunk plan exceeds its bound");
     }
     ChunkCtl cc{nullptr, nullptr, nullptr, n_vr ? SCAN_LONG : 0u};
     if ((rc = launch_scan(h, d_packed, d_starts, n_reads, out, query_mode, plain, cc))) return rc;
     if (n_vr) {
-        // records of the short reads are in [0, n1); the chunked launch appends after them and tags its records
+        // records of the short reads are in [0, n1); the chunked launch appends after them and tags its records with
+        // their chunk; seeded re-scans append after those
         HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         const u64 n1 = std::min<u64>(h->h_small[0], cap);
         if ((rc = ensure(h, h->tags_a, cap * 4))) return rc;
-        HIPCHK(h, hipMemsetAsync(d_spec, 0, (2 * cap_vr + 1) * sizeof(ChunkState), h->stream));
-        HIPCHK(h, hipMemsetAsync(d_bad, 0, (n_reads + 1) * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(d_spec, 0, (2 * cap_vr + 1) * sizeof(ChunkState) + 2 * cap_vr * 4, h->stream));  // states, status, cursor
+        HIPCHK(h, hipMemsetAsync(d_stop, 0xff, cap_vr * 4, h->stream));
         ScanOut out2 = out;
         out2.tag = (u32*)h->tags_a.p;
         ChunkCtl c2{d_vr, d_spec, d_truth, 0u};
         if ((rc = launch_scan(h, d_packed, d_starts, n_vr, out2, false, false, c2))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_verify_chunks, dim3(nblocks(n_vr, 256)), dim3(256), 0, h->stream, d_vr, d_spec, d_truth, n_vr, d_bad, (u32*)(h->d_small + 7));
-        if (int lrc = launch_check(h, "k_verify_chunks")) return lrc;
         HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const u32 n_bad = (u32)h->h_small[7];
-        if (n_bad && !(u32)h->h_small[1]) {
-            // a seam did not match: drop what the chunks of those sequences emitted and scan them whole (one lane each)
-            const u64 n2 = std::min<u64>(h->h_small[0], cap);
-            if ((rc = ensure(h, h->parted, (n2 - n1 + 1) * h->P.stride * 8))) return rc;
-            HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
-            hipLaunchKernelGGL(k_filter_records, dim3(nblocks(n2 - n1, 256)), dim3(256), 0, h->stream, h->P, d_rec, (const u32*)h->tags_a.p, n1, n2, d_bad,
-                               (u64*)h->parted.p, h->d_small + 6);
-            if (int lrc = launch_check(h, "k_filter_records")) return lrc;
-            HIPCHK(h, hipMemcpyAsync(h->h_small + 6, h->d_small + 6, 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            const u64 kept = h->h_small[6];
-            if (kept) HIPCHK(h, hipMemcpyAsync(d_rec + n1 * h->P.stride, h->parted.p, kept * h->P.stride * 8, hipMemcpyDeviceToDevice, h->stream));
-            h->h_small[6] = n1 + kept;  // pinned: stays untouched until the copy below has run
-            HIPCHK(h, hipMemcpyAsync(h->d_small, h->h_small + 6, 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+        const u64 n2 = std::min<u64>(h->h_small[0], cap);
+        ScanOut out3 = out2;
+        out3.hist = nullptr;  // once a chunk is re-scanned the histogram is rebuilt from the final records
+        u64 total_rerun = 0;
+        u32 rounds = 0;
+        for (;; rounds++) {  // one round per mismatch along a sequence; no mismatch: one round
             HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
-            hipLaunchKernelGGL(k_bad_vreads, dim3(nblocks(n_reads, 256)), dim3(256), 0, h->stream, d_starts, n_reads, d_bad, d_vr, (u32*)(h->d_small + 7));
-            if (int lrc = launch_check(h, "k_bad_vreads")) return lrc;
-            ScanOut out3 = out;
-            out3.hist = nullptr;  // the histogram is rebuilt from the final records
-            ChunkCtl c3{d_vr, d_spec, d_truth, 0u};
-            if ((rc = launch_scan(h, d_packed, d_starts, n_bad, out3, false, false, c3))) return rc;
+            hipLaunchKernelGGL(k_chunk_match, dim3(nblocks(n_vr, 256)), dim3(256), 0, h->stream, d_vr, d_spec, d_truth, n_vr, d_cursor, d_stop);
+            hipLaunchKernelGGL(k_chunk_commit, dim3(nblocks(n_vr, 256)), dim3(256), 0, h->stream, d_vr, n_vr, chunk, (u32)h->P.k, (u32)h->P.w, d_starts, d_cursor,
+                               d_stop, d_status, d_rerun, (u32*)(h->d_small + 7));
+            hipLaunchKernelGGL(k_chunk_next, dim3(nblocks(n_vr, 256)), dim3(256), 0, h->stream, d_vr, n_vr, d_cursor, d_stop);
+            if (int lrc = launch_check(h, "k_chunk_match/commit/next")) return lrc;
+            HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const u32 n_rerun = (u32)h->h_small[7];
+            if (!n_rerun) break;
+            total_rerun += n_rerun;
+            ChunkCtl c3{d_rerun, d_spec, d_truth, 0u};
+            if ((rc = launch_scan(h, d_packed, d_starts, n_rerun, out3, false, false, c3))) return rc;
+        }
+        static const bool dbg_chunks = getenv("BRISK_DEBUG_CHUNKS") != nullptr;
+        if (dbg_chunks) fprintf(stderr, "[brisk_hip] chunked scan: %u chunks of %u steps, %llu seeded re-scans in %u rounds\n", n_vr, chunk,
+                                (unsigned long long)total_rerun, rounds);
+        if (total_rerun) {
+            HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (!(u32)h->h_small[1]) {
+                // drop what the re-scanned chunks emitted speculatively ([n1, n2)); what the seeded scans emitted ([n2, n3)) stays
+                const u64 n3 = std::min<u64>(h->h_small[0], cap);
+                if ((rc = ensure(h, h->parted, (n3 - n1 + 1) * h->P.stride * 8))) return rc;
+                HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
+                hipLaunchKernelGGL(k_filter_records, dim3(nblocks(n2 - n1, 256)), dim3(256), 0, h->stream, h->P, d_rec, (const u32*)h->tags_a.p, n1, n2, d_status,
+                                   (u64*)h->parted.p, h->d_small + 6);
+                if (int lrc = launch_check(h, "k_filter_records")) return lrc;
+                HIPCHK(h, hipMemcpyAsync(h->h_small + 6, h->d_small + 6, 8, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                const u64 kept = h->h_small[6];
+                char* stage = (char*)h->parted.p;
+                if (n3 > n2) HIPCHK(h, hipMemcpyAsync(stage + kept * h->P.stride * 8, d_rec + n2 * h->P.stride, (n3 - n2) * h->P.stride * 8, hipMemcpyDeviceToDevice, h->stream));
+                if (kept + n3 - n2) HIPCHK(h, hipMemcpyAsync(d_rec + n1 * h->P.stride, stage, (kept + n3 - n2) * h->P.stride * 8, hipMemcpyDeviceToDevice, h->stream));
+                h->h_small[6] = n1 + kept + (n3 - n2);  // pinned: stays untouched until the copy below has run
+                HIPCHK(h, hipMemcpyAsync(h->d_small, h->h_small + 6, 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
             if (hist_valid) *hist_valid = false;
         }
     }
@@ -522,17 +553,18 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
     return BRISK_HIP_OK;
 }
 
-int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out) {
-    HIPCHK(h, hipMemsetAsync(h->d_small + 4, 0, 8, h->stream));
+int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out, u64* out_long = nullptr) {
+    HIPCHK(h, hipMemsetAsync(h->d_small + 4, 0, 16, h->stream));
     {
         ProfScope ps(h, S_COUNT);
         const u32 grid = std::min<u32>(nblocks(n_reads, 256), 4096);
         hipLaunchKernelGGL(k_count_kmers, dim3(grid ? grid : 1), dim3(256), 0, h->stream, d_starts, n_reads, h->P.k, h->d_small + 4);
         if (int lrc = launch_check(h, "k_count_kmers")) return lrc;
     }
-    HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->d_small + 4, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->d_small + 4, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *out = h->h_small[4];
+    if (out_long) *out_long = h->h_small[5];
     return BRISK_HIP_OK;
 }
 
@@ -540,13 +572,14 @@ int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out) 
 int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool with_hist, bool query_mode,
                     u64* n_rec_out, bool* hist_valid = nullptr) {
     int rc;
-    u64 bound = 0;
-    if ((rc = count_kmers(h, d_starts, n_reads, &bound))) return rc;
+    u64 bound = 0, in_long = 0;
+    if ((rc = count_kmers(h, d_starts, n_reads, &bound, &in_long))) return rc;
     if (bound == 0) {
         *n_rec_out = 0;
         return BRISK_HIP_OK;
     }
-    u64 cap = std::min<u64>(bound, n_reads * 8 + 4096);
+    // first try: a few records per short read, one per ~(w+2)/2 k-mers of a long one (twice that, for slack)
+    u64 cap = std::min<u64>(bound, n_reads * 8 + 4 * in_long / (h->P.w + 2) + 4096);
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = ensure(h, h->staging, cap * h->P.stride * 8))) return rc;
         u32* tags = nullptr;

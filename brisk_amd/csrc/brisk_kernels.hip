@@ -83,19 +83,33 @@ __global__ void __launch_bounds__(256) k_synth(u64 genome_len, u64 first_read, u
     packed[w] = v;
 }
 
-// sum over reads of max(0, len-k+1): the number of k-mer instances (an upper
-// bound on records).  One atomic per block.
+// out[0] = sum over reads of max(0, len-k+1): the number of k-mer instances (an upper bound on records);
+// out[1] = the share of it in reads of more than 1024 k-mers (a record every ~(w+2)/2 k-mers there, while a
+// short read makes a few records whatever its length).  One atomic pair per block.
 __global__ void __launch_bounds__(256) k_count_kmers(const u64* __restrict__ starts, u64 n_reads, u32 k, unsigned long long* out) {
-    __shared__ unsigned long long s_sum[4];
-    unsigned long long acc = 0;
+    __shared__ unsigned long long s_sum[4], s_long[4];
+    unsigned long long acc = 0, lng = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
         const u64 len = starts[r + 1] - starts[r];
-        if (len >= k) acc += len - k + 1;
+        if (len >= k) {
+            acc += len - k + 1;
+            if (len - k + 1 > 1024) lng += len - k + 1;
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        lng += __shfl_down(lng, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[threadIdx.x >> 6] = acc;
+        s_long[threadIdx.x >> 6] = lng;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+    if (threadIdx.x == 0) {
+        atomicAdd(out, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        const unsigned long long l = s_long[0] + s_long[1] + s_long[2] + s_long[3];
+        if (l) atomicAdd(out + 1, l);
+    }
 }
 
 // ===========================================================================
@@ -347,22 +361,29 @@ __device__ __forceinline__ u64 read_lane_u64(u64 v, int L) {
 }
 
 // ---- long sequences: scanned as overlapping chunks, each chunk a "virtual read" ----------------
-// The enumerator's state (minimizer key, its position, its strand) at a step depends on history, so a
-// chunk starts SCAN_WARMUP steps early from a fresh state, emits only the vectors that start inside
-// its own window [emit_from, emit_until), and records the state it had reached at emit_from; the
-// previous chunk records the state it had at the same step.  Equal states => everything the chunk
-// emitted is exactly what one sequential pass emits.  A sequence with a mismatch (long runs where no
-// new minimum ever arrives keep two runs out of phase) is re-scanned whole by one lane.
+// The enumerator's state (minimizer key, its position, its strand) before a step depends on history, so a
+// chunk starts SCAN_WARMUP steps early from a fresh state, emits only the vectors that start inside its
+// own window [emit_from, emit_until), and exports the state it had reached at emit_from (spec); its
+// predecessor exports the state it had at the same step (truth).  Equal state + same nucleotides =>
+// identical stream from there on.  A chunk is EXACT when its predecessor is exact and the two states
+// match (the first chunk of a sequence is exact by definition); matching against a predecessor that is
+// itself wrong proves nothing (two cold starts can agree with each other inside a periodic region and
+// both be out of phase with the sequential run).  A chunk whose states do not match is scanned again
+// from its window's first step, SEEDED with the exact state its predecessor exported: no warm-up, no
+// speculation.  k_chunk_match / k_chunk_commit extend exactness along every sequence as far as it reaches and
+// list the chunks to re-scan; the host repeats until every chunk is exact (one round per mismatch along a
+// sequence: long runs without a new minimum -- homopolymers, short tandem repeats).
 #define SCAN_LONG 8192u     // sequences with more k-mers than this are chunked
-#define SCAN_CHUNK 4096u    // steps (k-mers) per chunk
-#define SCAN_WARMUP 512u    // steps a chunk runs before its window
+#define SCAN_WARMUP 512u    // steps a speculative chunk runs before its window
 struct VRead {
     u64 q0;          // stream index of the virtual read's first nt
     u32 len;         // nts
     u32 emit_from;   // local step of the first vector start that belongs to this chunk
     u32 emit_until;  // local step bound (exclusive); ~0u: to the end of the sequence
     u32 read;        // index of the sequence in the batch
-    u32 flags;       // 1: starts at the sequence's first nt, 2: runs to its last k-mer
+    u32 flags;       // 1: first chunk of its sequence, 2: runs to the sequence's last k-mer, 4: seeded start
+    u32 slot;        // chunk index: where its states live, and the tag of its records
+    u32 first;       // chunk index of its sequence's first chunk
     u32 pad;
 };
 struct ChunkState {
@@ -372,74 +393,118 @@ struct ChunkState {
 };
 struct ChunkCtl {
     const VRead* vreads;   // null: whole reads from `starts`
-    ChunkState* spec;      // [n_vreads]   state a chunk reached at its emit_from
-    ChunkState* truth;     // [n_vreads+1] state the previous chunk had at the same step
+    ChunkState* spec;      // [n_chunks]   state a speculative chunk reached at its emit_from
+    ChunkState* truth;     // [n_chunks+1] state the previous chunk had at the same step; seed of a seeded chunk
     u32 long_limit;        // whole-read launch: skip reads with more k-mers than this (0: none)
 };
+#define CHUNK_EXACT 1u      // chunk status bits
+#define CHUNK_RERUN 2u      // its speculative records are void, a seeded scan replaced them
 
-// one thread per read: plan the chunks of long reads (consecutive slots per read)
-__global__ void __launch_bounds__(256) k_plan_chunks(const u64* __restrict__ starts, u64 n_reads, u32 k, u32 w, VRead* __restrict__ vreads,
-                                                     u32 cap, u32* __restrict__ n_vreads) {
+// plan the chunks of long reads (consecutive slots per read): one thread per read reserves the slots, then one
+// block per long read writes them (a chromosome is ~10^5 chunks)
+struct LongRead {
+    u32 read, base, n_chunks, pad;
+};
+__global__ void __launch_bounds__(256) k_plan_chunks(const u64* __restrict__ starts, u64 n_reads, u32 k, u32 chunk, u32 cap, u32* __restrict__ n_vreads,
+                                                     LongRead* __restrict__ longs, u32* __restrict__ n_long) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    const u64 q0 = starts[r], len = starts[r + 1] - q0;
+    const u64 len = starts[r + 1] - starts[r];
     if (len < k) return;
     const u64 nk = len - k + 1;
     if (nk <= SCAN_LONG) return;
-    const u32 nc = (u32)((nk + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    const u32 nc = (u32)((nk + chunk - 1) / chunk);
     const u32 base = atomicAdd(n_vreads, nc);
     if (base + nc > cap) return;  // cannot happen: cap is the bound the host computed
-    for (u32 c = 0; c < nc; c++) {
-        const u64 b0 = (u64)c * SCAN_CHUNK, b1 = b0 + SCAN_CHUNK;
-        const u64 s0 = c == 0 ? 0 : b0 - SCAN_WARMUP;
-        const bool last = b1 >= nk;
-        const u64 end_step = last ? nk : (b1 + w + 2 < nk ? b1 + w + 2 : nk);
-        VRead v;
-        v.q0 = q0 + s0;
-        v.len = (u32)(end_step - s0 + k - 1);
-        v.emit_from = (u32)(b0 - s0);
-        v.emit_until = last ? 0xffffffffu : (u32)(b1 - s0);
-        v.read = (u32)r;
-        v.flags = (c == 0 ? 1u : 0u) | (end_step == nk ? 2u : 0u);  // bit 1: this virtual read runs to the sequence's last k-mer
-        v.pad = 0;
-        vreads[base + c] = v;
+    longs[atomicAdd(n_long, 1u)] = LongRead{(u32)r, base, nc, 0u};
+}
+__global__ void __launch_bounds__(256) k_fill_chunks(const u64* __restrict__ starts, u32 k, u32 w, u32 chunk, const LongRead* __restrict__ longs, u32 n_long,
+                                                     VRead* __restrict__ vreads) {
+    for (u32 li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const LongRead lr = longs[li];
+        const u64 q0 = starts[lr.read], nk = starts[lr.read + 1] - q0 - k + 1;
+        for (u32 c = threadIdx.x; c < lr.n_chunks; c += blockDim.x) {
+            const u64 b0 = (u64)c * chunk, b1 = b0 + chunk;
+            const u64 s0 = c == 0 ? 0 : b0 - SCAN_WARMUP;
+            const bool last = b1 >= nk;
+            const u64 end_step = last ? nk : (b1 + w + 2 < nk ? b1 + w + 2 : nk);
+            VRead v;
+            v.q0 = q0 + s0;
+            v.len = (u32)(end_step - s0 + k - 1);
+            v.emit_from = (u32)(b0 - s0);
+            v.emit_until = last ? 0xffffffffu : (u32)(b1 - s0);
+            v.read = lr.read;
+            v.flags = (c == 0 ? 1u : 0u) | (end_step == nk ? 2u : 0u);
+            v.slot = lr.base + c;
+            v.first = lr.base;
+            v.pad = 0;
+            vreads[lr.base + c] = v;
+        }
     }
 }
-// chunk c's speculative start state must equal what chunk c-1 had at that step
-__global__ void __launch_bounds__(256) k_verify_chunks(const VRead* __restrict__ vreads, const ChunkState* __restrict__ spec,
-                                                       const ChunkState* __restrict__ truth, u32 n_vreads, u32* __restrict__ bad_read, u32* __restrict__ n_bad) {
+// One round of the exactness walk, one thread per chunk (a single chromosome is ~10^5 chunks: no serial walk).
+// cursor[first] = first chunk of the sequence not yet known exact; stop[first] = first chunk at or after the
+// cursor whose speculative state does not match what its predecessor exported.  Chunks in [cursor, stop) are
+// exact by induction (each matches the export of an exact predecessor); chunk `stop` is queued for a seeded
+// re-scan from the exact state in truth[stop]; the walk resumes behind it in the next round.
+__global__ void __launch_bounds__(256) k_chunk_match(const VRead* __restrict__ vreads, const ChunkState* __restrict__ spec,
+                                                     const ChunkState* __restrict__ truth, u32 n_chunks, const u32* __restrict__ cursor,
+                                                     u32* __restrict__ stop) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_vreads) return;
-    const VRead v = vreads[i];
-    if (v.flags & 1u) return;
+    if (i >= n_chunks) return;
+    const u32 f = vreads[i].first;
+    const u32 c = cursor[f] > f + 1 ? cursor[f] : f + 1;
+    if (i < c) return;
     const ChunkState a = spec[i], b = truth[i];
-    if (!(a.set && b.set && a.hash == b.hash && a.pos_rev == b.pos_rev)) {
-        if (atomicExch(&bad_read[v.read], 1u) == 0u) atomicAdd(n_bad, 1u);
-    }
+    if (!(a.set && b.set && a.hash == b.hash && a.pos_rev == b.pos_rev)) atomicMin(&stop[f], i);
 }
-// drop the records of sequences that must be re-scanned; whole-read descriptors for those sequences
+__global__ void __launch_bounds__(256) k_chunk_commit(const VRead* __restrict__ vreads, u32 n_chunks, u32 chunk, u32 k, u32 w,
+                                                      const u64* __restrict__ starts, const u32* __restrict__ cursor, const u32* __restrict__ stop,
+                                                      u32* __restrict__ status, VRead* __restrict__ rerun, u32* __restrict__ n_rerun) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks) return;
+    const VRead me = vreads[i];
+    const u32 f = me.first;
+    const u32 c = cursor[f] > f + 1 ? cursor[f] : f + 1;
+    const u32 st = stop[f];
+    if (i == f) status[i] |= CHUNK_EXACT;
+    if (i < c || i > st) return;
+    if (i < st) {
+        status[i] |= CHUNK_EXACT;
+        return;
+    }
+    // i == st: scan this chunk again from its window's first step, from the exact state in truth[i]
+    const u64 q0 = starts[me.read], nk = starts[me.read + 1] - q0 - k + 1;
+    const u64 b0 = (u64)(i - f) * chunk, b1 = b0 + chunk;
+    const bool last = b1 >= nk;
+    const u64 end_step = last ? nk : (b1 + w + 2 < nk ? b1 + w + 2 : nk);
+    VRead v;
+    v.q0 = q0 + b0;
+    v.len = (u32)(end_step - b0 + k - 1);
+    v.emit_from = 0;
+    v.emit_until = last ? 0xffffffffu : (u32)(b1 - b0);
+    v.read = me.read;
+    v.flags = 4u | (end_step == nk ? 2u : 0u);
+    v.slot = i;
+    v.first = f;
+    v.pad = 0;
+    rerun[atomicAdd(n_rerun, 1u)] = v;
+    status[i] = CHUNK_EXACT | CHUNK_RERUN;  // exact once the re-scan launched after this kernel has run
+}
+__global__ void __launch_bounds__(256) k_chunk_next(const VRead* __restrict__ vreads, u32 n_chunks, u32* __restrict__ cursor, u32* __restrict__ stop) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks || vreads[i].first != i) return;
+    cursor[i] = stop[i] == 0xffffffffu ? 0xffffffffu : stop[i] + 1;
+    stop[i] = 0xffffffffu;
+}
+// keep the speculative records of the chunks that were not re-scanned
 __global__ void __launch_bounds__(256) k_filter_records(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags, u64 first, u64 n_rec,
-                                                        const u32* __restrict__ bad_read, u64* __restrict__ out, unsigned long long* __restrict__ n_out) {
+                                                        const u32* __restrict__ status, u64* __restrict__ out, unsigned long long* __restrict__ n_out) {
     const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
-    if (bad_read[tags[i]]) return;
+    if (status[tags[i]] & CHUNK_RERUN) return;
     const unsigned long long slot = atomicAdd(n_out, 1ull);
     for (u32 j = 0; j < P.stride; j++) out[slot * P.stride + j] = rec[i * P.stride + j];
-}
-__global__ void __launch_bounds__(256) k_bad_vreads(const u64* __restrict__ starts, u64 n_reads, const u32* __restrict__ bad_read,
-                                                    VRead* __restrict__ vreads, u32* __restrict__ n_vreads) {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads || !bad_read[r]) return;
-    const u32 slot = atomicAdd(n_vreads, 1u);
-    VRead v;
-    v.q0 = starts[r];
-    v.len = (u32)(starts[r + 1] - v.q0);
-    v.emit_from = 0;
-    v.emit_until = 0xffffffffu;
-    v.read = (u32)r;
-    v.flags = 3u;
-    v.pad = 0;
-    vreads[slot] = v;
 }
 
 // closed form of get_minimizer's fold (Kmers.cpp:377-405) given the first and last window
@@ -501,8 +566,8 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     const u64 M = P.m_mask;
     const u64 r = (u64)blockIdx.x * blockDim.x + tid;
     u64 q0 = 0, len = 0;
-    u32 emit_from = 0, emit_until = 0xffffffffu, tagval = (u32)r;
-    bool seq_first = true, seq_last = true;
+    u32 emit_from = 0, emit_until = 0xffffffffu, tagval = (u32)r, vslot = 0;
+    bool seq_first = true, seq_last = true, seeded = false;
     if (r < n_reads) {
         if (cc.vreads) {
             const VRead v = cc.vreads[r];
@@ -510,9 +575,10 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             len = v.len;
             emit_from = v.emit_from;
             emit_until = v.emit_until;
-            tagval = v.read;
+            tagval = vslot = v.slot;
             seq_first = v.flags & 1u;
             seq_last = v.flags & 2u;
+            seeded = v.flags & 4u;
         } else {
             q0 = starts[r];
             len = starts[r + 1] - q0;
@@ -580,6 +646,13 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         mini_pos = pos;
         reversed = rev;
     }
+    if (seeded) {  // the exact state the previous chunk had before this step
+        const ChunkState st = cc.truth[vslot];
+        mini_hash = st.hash;
+        mini_pos = st.pos_rev & 0x7fffffffu;
+        reversed = st.pos_rev >> 31;
+    }
+    bool foreign = seeded;  // the vector open at a seeded start began before it: it is the previous chunk's
 
     // ---- the stream of k-mers
     u32 qcount = 0;  // wave-uniform
@@ -590,8 +663,8 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     for (u32 p = 0; p < max_nk; p++) {
         const bool act = p < nk && !dead;
         if (cc.vreads && live) {  // the enumerator state before step p, for the chunk-seam check
-            if (p == emit_from && !seq_first) cc.spec[r] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
-            if (p == emit_until) cc.truth[r + 1] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
+            if (p == emit_from && !seq_first && !seeded) cc.spec[vslot] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
+            if (p == emit_until) cc.truth[vslot + 1] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
         }
         if ((p & 31) == 0 && p < nk) {
             const u32 left = (u32)(len - (k - 1 + p));
@@ -610,7 +683,8 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
         const bool closed = expired || newmin;
         // the vector closed by this step (Kmers.cpp:585-588); a close at p == 0 is ignored (:590-592)
-        bool push = closed && p > 0 && p0 >= emit_from && p0 < emit_until;  // a chunk emits the vectors that start in its window
+        bool push = closed && p > 0 && !foreign && p0 >= emit_from && p0 < emit_until;  // a chunk emits the vectors that start in its window
+        if (closed) foreign = false;
         if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) {  // counter.cpp:304-306: returned minimizer == 0
             push = false;
             dead = true;
@@ -696,7 +770,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         }
         if (act) {
             const u32 idx = reversed ? w - mini_pos : mini_pos;  // Kmers.cpp:578-584
-            if (closed && p > 0) n = 0;
+            if (closed && (p > 0 || seeded)) n = 0;  // a close at a seeded start is a real one: a new vector begins here
             if (n == 0) {
                 p0 = p;
                 first_idx = idx;
@@ -720,7 +794,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     // the last vector of every read (Kmers.cpp:596-601)
     {
         // the sequence's true end closes the open vector; it belongs to the chunk in whose window it started
-        bool push = live && !dead && n > 0 && seq_last && p0 >= emit_from && p0 < emit_until;
+        bool push = live && !dead && n > 0 && seq_last && !foreign && p0 >= emit_from && p0 < emit_until;
         if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) push = false;
         const unsigned long long bal = __ballot(push);
         if (push) {
