@@ -1149,6 +1149,7 @@ struct IndexDev {
 #define WI_MAX_INST 256     // k-mer instances per chunk
 #endif
 #define WI_TABLE (2 * WI_MAX_INST)   // LDS table slots (load <= 0.5)
+static_assert(WI_MAX_INST % 256 == 0 && WI_MAX_INST <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
 #define WI_MAX_REC 64       // records per chunk: one per lane
 #define WI_CNT_SHIFT 10     // table word = [MATCHED | multiplicity (21 b) | instance (10 b)]
 #define WI_IDX_MASK 0x3ffu
@@ -1176,13 +1177,35 @@ __device__ __forceinline__ RecRegs load_rec_regs(const BriskParams& P, const u64
     }
     return r;
 }
-__device__ __forceinline__ u32 wave_incl_scan(u32 x, u32 lane) {
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 y = __shfl_up(x, o, 64);
-        if ((int)lane >= o) x += y;
+// Inclusive scans over the 64 lanes on the DPP network: row_shr 1,2,4,8 inside each row of 16, then row_bcast15
+// and row_bcast31 carry the row totals over.  Lanes without a source keep the identity 0.  Full EXEC mask only.
+#define WAVE_SCAN_STEP(x, OP, CTRL, ROW_MASK)                                                         \
+    {                                                                                                 \
+        const u32 y_ = (u32)__builtin_amdgcn_update_dpp(0, (int)(x), CTRL, ROW_MASK, 0xf, false); \
+        x = OP(x, y_);                                                                                \
     }
+__device__ __forceinline__ u32 op_add_u32(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 op_max_u32(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 wave_incl_scan(u32 x, u32 /*lane*/) {
+    WAVE_SCAN_STEP(x, op_add_u32, 0x111, 0xf)  // row_shr:1
+    WAVE_SCAN_STEP(x, op_add_u32, 0x112, 0xf)  // row_shr:2
+    WAVE_SCAN_STEP(x, op_add_u32, 0x114, 0xf)  // row_shr:4
+    WAVE_SCAN_STEP(x, op_add_u32, 0x118, 0xf)  // row_shr:8
+    WAVE_SCAN_STEP(x, op_add_u32, 0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    WAVE_SCAN_STEP(x, op_add_u32, 0x143, 0xc)  // row_bcast:31 -> rows 2, 3
     return x;
 }
+__device__ __forceinline__ u32 wave_incl_max_scan(u32 x) {
+    WAVE_SCAN_STEP(x, op_max_u32, 0x111, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x112, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x114, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x118, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x142, 0xa)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x143, 0xc)
+    return x;
+}
+// value of the previous lane (0 for lane 0)
+__device__ __forceinline__ u32 wave_prev_lane(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }  // wave_shr:1
 
 #define WI_NI (WI_MAX_INST / 64)   // instances per lane
 #define WI_TS (WI_TABLE / 64)      // table words per lane
@@ -1279,7 +1302,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
     u32* s_list = (u32*)s_rec;  // [WI_MAX_INST] the new entries' table words: built after the records have been expanded
     __shared__ u32 s_rtab[2 * WI_MAX_REC];
     __shared__ u32 s_rmult[WI_MAX_REC];
-    __shared__ uint8_t s_irec[WI_MAX_INST];
+    __shared__ __attribute__((aligned(4))) uint8_t s_irec[WI_MAX_INST];
+    __shared__ u32 s_bm[2];
 
     const u32 lane = threadIdx.x;
     unsigned long long acur = ix.slot_cur[blockIdx.x], aend = ix.slot_end[blockIdx.x], garbage = 0;
@@ -1337,9 +1361,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                     wave_sync();
                     bool dup = false;
                     if (lane < nrec) {
-                        u64 z = rr.w0 ^ (rr.w1 * 0x9E3779B97F4A7C15ull) ^ (rr.w2 * 0xC2B2AE3D27D4EB4Full) ^ (rr.w3 * 0x165667B19E3779F9ull) ^ (rr.w4 * 0xD6E8FEB86659FD93ull);
-                        z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
-                        u32 h = (u32)(z >> 40) & (2 * WI_MAX_REC - 1);
+                        // a weak hash is enough for <= 64 records in 128 slots: rotate-xor fold, one 32-bit multiply
+                        const u64 z = rr.w0 ^ ((rr.w1 << 17) | (rr.w1 >> 47)) ^ ((rr.w2 << 31) | (rr.w2 >> 33)) ^ ((rr.w3 << 47) | (rr.w3 >> 17)) ^ rr.w4;
+                        u32 h = ((((u32)z ^ (u32)(z >> 32)) * 0x9E3779B1u) >> 20) & (2 * WI_MAX_REC - 1);
                         for (;;) {
                             const u32 o = atomicCAS(&s_rtab[h], EMPTY_SLOT, lane);
                             if (o == EMPTY_SLOT) break;
@@ -1372,8 +1396,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 for (u32 w = 0; w < WI_TS; w++)
                     if (w * 64 < tsize) s_tab[w * 64 + lane] = EMPTY_SLOT;
                 {
-                    const u32 start = x - my_n;
-                    for (u32 j = 0; j < my_n; j++) s_irec[start + j] = (uint8_t)lane;
+                    // instance -> record: each record marks its first instance, a running maximum spreads the marks
+                    // (records lie in lane order).  Every lane owns WI_MAX_INST/64 consecutive instances here.
+                    u32* irec32 = (u32*)s_irec;
+#pragma unroll
+                    for (u32 q = 0; q < WI_MAX_INST / 256; q++) irec32[q * 64 + lane] = 0;
+                    wave_sync();
+                    if (my_n) s_irec[x - my_n] = (uint8_t)(lane + 1);
+                    wave_sync();
+                    u32 wv[WI_MAX_INST / 256], run = 0;
+#pragma unroll
+                    for (u32 q = 0; q < WI_MAX_INST / 256; q++) {
+                        wv[q] = irec32[lane * (WI_MAX_INST / 256) + q];
+                        run = op_max_u32(run, op_max_u32(op_max_u32(wv[q] & 0xff, (wv[q] >> 8) & 0xff), op_max_u32((wv[q] >> 16) & 0xff, wv[q] >> 24)));
+                    }
+                    u32 carry = wave_prev_lane(wave_incl_max_scan(run));  // the last mark before this lane's instances
+#pragma unroll
+                    for (u32 q = 0; q < WI_MAX_INST / 256; q++) {
+                        const u32 b0 = op_max_u32(carry, wv[q] & 0xff), b1 = op_max_u32(b0, (wv[q] >> 8) & 0xff);
+                        const u32 b2 = op_max_u32(b1, (wv[q] >> 16) & 0xff), b3 = op_max_u32(b2, wv[q] >> 24);
+                        carry = b3;
+                        // marks are lane + 1; instances past the last record (none are read) may hold 0 - 1
+                        irec32[lane * (WI_MAX_INST / 256) + q] = ((b0 - 1) & 0xff) | (((b1 - 1) & 0xff) << 8) | (((b2 - 1) & 0xff) << 16) | ((b3 - 1) << 24);
+                    }
                 }
                 wave_sync();
                 // the next partition's first records: requested now, consumed next iteration
@@ -1479,9 +1524,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 rc += nrec;
 
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                bm0 |= __shfl_xor(bm0, o, 64);
-                bm1 |= __shfl_xor(bm1, o, 64);
+            if (P.shift <= 6) {  // OR the lanes' bucket bits together through LDS
+                if (lane < 2) s_bm[lane] = 0;
+                wave_sync();
+                if (bm0) atomicOr(&s_bm[0], bm0);
+                if (bm1) atomicOr(&s_bm[1], bm1);
+                wave_sync();
+                bm0 = s_bm[0];
+                bm1 = s_bm[1];
             }
             if (lane == 0) ix.dir[part] = DirEnt{off, n_exist, cap};
             // bucket occupancy bits: exact when a partition holds <= 64 buckets (shift <= 6);
