@@ -213,7 +213,7 @@ class BriskHip:
             self.h = C.c_void_p()
 
     def __del__(self):
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():  # module globals are already gone late in interpreter shutdown
             return
         try:
             self.close()
