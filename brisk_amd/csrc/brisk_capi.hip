@@ -425,12 +425,24 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     } else {
         const u32 bt = h->scan_waves * 64;
         const dim3 grid(nblocks(n_items, bt)), block(bt);
-        const int qm = query_mode ? 1 : 0;
-        switch (h->scfg.nch) {  // unrolled table lookups for the common minimizer sizes
-            case 5: hipLaunchKernelGGL(k_scan2<5>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, qm, cc); break;
-            case 3: hipLaunchKernelGGL(k_scan2<3>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, qm, cc); break;
-            default: hipLaunchKernelGGL(k_scan2<0>, grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, qm, cc);
-        }
+        // instantiations: chunk-table count nch = ceil((m-1)/4) (5: m 18..21, 3: m 10..13, else generic) x mode x
+        // {k and m compile-time for the two common parameter sets, or from P}
+#define LAUNCH_SCAN2(NCH, MODE, KK, MM) \
+    hipLaunchKernelGGL((k_scan2<NCH, MODE, KK, MM>), grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, cc)
+#define LAUNCH_SCAN2_MODES(NCH, KK, MM)                    \
+    {                                                      \
+        if (cc.vreads) LAUNCH_SCAN2(NCH, 2, KK, MM);       \
+        else if (query_mode) LAUNCH_SCAN2(NCH, 1, KK, MM); \
+        else LAUNCH_SCAN2(NCH, 0, KK, MM);                 \
+    }
+        const u32 k = h->P.k, m = h->P.m;
+        if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(5, 63, 21)
+        else if (k == 31 && m == 11) LAUNCH_SCAN2_MODES(3, 31, 11)
+        else if (h->scfg.nch == 5) LAUNCH_SCAN2_MODES(5, 0, 0)
+        else if (h->scfg.nch == 3) LAUNCH_SCAN2_MODES(3, 0, 0)
+        else LAUNCH_SCAN2_MODES(0, 0, 0)
+#undef LAUNCH_SCAN2_MODES
+#undef LAUNCH_SCAN2
     }
     return launch_check(h, "k_scan");
 }
@@ -832,9 +844,10 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             static size_t lds_attr = 0;
             if (h->scan_lds > lds_attr) {
                 lds_attr = h->scan_lds;
-                HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
-                HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
-                HIPCHK(h, hipFuncSetAttribute((const void*)k_scan2<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+#define SCAN2_FNS(NCH, KK, MM) (const void*)k_scan2<NCH, 0, KK, MM>, (const void*)k_scan2<NCH, 1, KK, MM>, (const void*)k_scan2<NCH, 2, KK, MM>
+                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(5, 0, 0), SCAN2_FNS(3, 31, 11), SCAN2_FNS(5, 63, 21)};
+#undef SCAN2_FNS
+                for (const void* fn : fns) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
             }
             const char* v1 = getenv("BRISK_SCAN_V1");
             h->scan_v1 = v1 && v1[0] == '1';

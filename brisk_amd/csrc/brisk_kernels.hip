@@ -546,14 +546,18 @@ __device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32
     }
 }
 
-template <int NCH>
+// MODE 0: reads, insert; 1: reads, query (stops a read at a returned minimizer of 0); 2: virtual reads (chunks of long sequences)
+// KK, MM: k and m as compile-time constants for the common parameter sets (0: from P) -- folds the shifts and masks and,
+// above all, frees scalar registers: the generic kernel spills 70+ of them into vector lanes and pays a v_readlane per use
+template <int NCH, int MODE, int KK, int MM>
 __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
-                                                u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, int query_mode, ChunkCtl cc) {
+                                                u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, ChunkCtl cc) {
+    constexpr bool VR = MODE == 2, query_mode = MODE == 1;
     extern __shared__ double smem_d[];
     double* s_coef = smem_d;             // 128
     double* s_tabs = smem_d + 128;       // 2*nch*256
     const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const u32 n_tab = 128 + 2 * cfg.nch * 256;
+    const u32 n_tab = 128 + 2 * (NCH ? (u32)NCH : cfg.nch) * 256;
     for (u32 i = tid; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
     unsigned long long* s_wbase = (unsigned long long*)(smem_d + n_tab);      // block's slot base at the final flush
     u32* s_wcnt = (u32*)(s_wbase + 1);                                         // [16] records left per wave
@@ -562,14 +566,15 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     u32* q_tag = q_misc + cfg.qcap;                // [qcap] read index
     __syncthreads();
 
-    const u32 k = P.k, m = P.m, w = P.w, nch = cfg.nch;
-    const u64 M = P.m_mask;
+    const u32 k = KK ? (u32)KK : P.k, m = MM ? (u32)MM : P.m, w = k - m, nch = NCH ? (u32)NCH : cfg.nch;
+    const u64 M = MM ? ((1ull << (2 * MM)) - 1) : P.m_mask;
+    const u32 nlow = k < 32 ? k : 32, nlow1 = k - 1 < 32 ? k - 1 : 32;  // nts of a k-mer / (k-1)-mer that get_minimizer sees (F2)
     const u64 r = (u64)blockIdx.x * blockDim.x + tid;
     u64 q0 = 0, len = 0;
     u32 emit_from = 0, emit_until = 0xffffffffu, tagval = (u32)r, vslot = 0;
     bool seq_first = true, seq_last = true, seeded = false;
     if (r < n_reads) {
-        if (cc.vreads) {
+        if (VR) {
             const VRead v = cc.vreads[r];
             q0 = v.q0;
             len = v.len;
@@ -601,7 +606,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
 
     // ---- prologue: the low 64 bits of the (k-1)-mer; its last m-mer seeds the rolling candidates
     u64 cf = 0, cr = 0, low64 = 0;
-    if (live) low64 = load_nts(packed, q0 + (k - 1) - cfg.nlow1, cfg.nlow1);
+    if (live) low64 = load_nts(packed, q0 + (k - 1) - nlow1, nlow1);
     cf = low64 & M;
     cr = rc64(cf, m);
 
@@ -617,7 +622,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         for (u32 i = 0; i <= Km; i++) {
             u64 key;
             bool rv;
-            if (i < cfg.nlow1) {  // inside the low 64 bits; windows that stick out of them are zero-padded (F2)
+            if (i < nlow1) {  // inside the low 64 bits; windows that stick out of them are zero-padded (F2)
                 const u64 fwd = (low64 >> (2 * i)) & M;
                 const u64 rcv = rc64(fwd, m);
                 rv = rcv < fwd;
@@ -662,7 +667,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     const u32 Km = k - m;
     for (u32 p = 0; p < max_nk; p++) {
         const bool act = p < nk && !dead;
-        if (cc.vreads && live) {  // the enumerator state before step p, for the chunk-seam check
+        if (VR && live) {  // the enumerator state before step p, for the chunk-seam check
             if (p == emit_from && !seq_first && !seeded) cc.spec[vslot] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
             if (p == emit_until) cc.truth[vslot + 1] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
         }
@@ -721,7 +726,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             const u64 rcv = rc64(fwd, m);
             const bool rv = rcv < fwd;
             u64 key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
-            if (wl > Km || wl >= cfg.nlow) key = ~0ull;
+            if (wl > Km || wl >= nlow) key = ~0ull;
             u64 hm = key;  // minimum of this lane's half
             for (int o = 16; o > 0; o >>= 1) {
                 const u64 y = __shfl_xor(hm, o, 64);
