@@ -204,8 +204,10 @@ def pmc_traffic(kernel, k, m, b, n_reads):
     w = d.get("workload", {})
     if (w.get("k"), w.get("m"), w.get("b"), w.get("reads")) != (k, m, b, n_reads):
         return None
-    name = {"k_scan": "k_scan2<5>"}.get(kernel, kernel)
-    e = d.get("kernels", {}).get(name)
+    kernels = d.get("kernels", {})
+    # the scan is a template: its profile name carries the instantiation (k_scan2<nch, mode, k, m>)
+    name = next((n for n in kernels if n.startswith("k_scan2<")), kernel) if kernel == "k_scan" else kernel
+    e = kernels.get(name)
     if not e or not e.get("launches"):
         return None
     return round((e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024 / e["launches"])
