@@ -60,6 +60,7 @@ struct brisk_hip_index {
     bool scan_v1 = false;       // BRISK_SCAN_V1=1: the plain restatement kernel
     bool entry_ids = false;
     bool use_vmm = false;
+    bool scan_hist_valid = false;  // d_hist holds the per-partition histogram of the last brisk_hip_scan_packed
     u64 arena_limit = 0;        // BRISK_ARENA_LIMIT (entries): artificial ceiling, for tests of the out-of-memory path
     VmBuf vm_keys, vm_counts, vm_ids;
     unsigned long long* d_id_counter = nullptr;
@@ -359,6 +360,7 @@ int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
 }
 
 int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist) {
+    h->scan_hist_valid = false;  // d_hist is this batch's from here on
     if (n_rec == 0) return BRISK_HIP_OK;
     if (n_rec >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
     const BriskParams& P = h->P;
@@ -453,7 +455,10 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
 int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, u64* d_rec, u64 cap, bool with_hist,
               bool query_mode, u32* d_tags, u64* n_rec_out, u64* d_ret = nullptr, u64 kmer_bound = 0, bool* hist_valid = nullptr) {
     if (hist_valid) *hist_valid = with_hist;
-    if (with_hist) HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+    if (with_hist) {
+        h->scan_hist_valid = false;
+        HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+    }
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
     ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret};
     const bool plain = h->scan_v1 || d_ret;
@@ -633,6 +638,7 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
 
 int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums) {
     const BriskParams& P = h->P;
+    h->scan_hist_valid = false;
     int rc;
     if ((rc = prefix_partitions(h, h->n_parts))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
@@ -1170,9 +1176,53 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     u64 bound = 0;
     int rc = count_kmers(h, d_starts, n_reads, &bound);
     if (rc) return rc;
-    rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, false, nullptr, &n, nullptr, bound);
+    // a sharded index keeps the per-partition histogram of what it scanned: the owners need it (export_hist)
+    const bool want_hist = h->P.n_owners > 1;
+    bool hist_ok = false;
+    h->scan_hist_valid = false;
+    rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, want_hist, false, nullptr, &n, nullptr, bound, &hist_ok);
     *n_records = n;
+    if (rc == BRISK_HIP_OK && want_hist) {
+        if (!hist_ok && n) {  // a long sequence was re-scanned in places: rebuild from the final records
+            HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+            hipLaunchKernelGGL(k_part_hist, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->P, d_records, n, h->d_hist);
+            if (int lrc = launch_check(h, "k_part_hist")) return lrc;
+        }
+        h->scan_hist_valid = true;
+    }
     return rc;
+}
+
+// first partition of owner o's range: the smallest p with p * N >> part_bits == o
+static u64 owner_first_partition(const BriskParams& P, u32 o) { return (((u64)o << P.part_bits) + P.n_owners - 1) / P.n_owners; }
+
+BRISK_API int brisk_hip_export_hist(brisk_hip_index* h, uint64_t* d_hist_out, uint64_t* partitions_per_owner) {
+    if (!h || !d_hist_out || !partitions_per_owner) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
+    HIPCHK(h, hipMemcpyAsync(d_hist_out, h->d_hist, h->n_parts * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h->P, o + 1) - owner_first_partition(h->P, o);
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_insert_records_hist(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_hist_slices, uint32_t n_slices) {
+    if (!h || (n_records && (!d_records || !d_hist_slices || !n_slices))) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
+    h->scan_hist_valid = false;
+    if (!n_records) return BRISK_HIP_OK;
+    const u64 p_lo = owner_first_partition(h->P, h->P.owner_rank), len = owner_first_partition(h->P, h->P.owner_rank + 1) - p_lo;
+    HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_small + 4, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_sum_slices, dim3(nblocks(len, 256)), dim3(256), 0, h->stream, (const unsigned long long*)d_hist_slices, n_slices, len, h->d_hist + p_lo,
+                       h->d_small + 4);
+    if (int lrc = launch_check(h, "k_sum_slices")) return lrc;
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->d_small + 4, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_small[4] != n_records) return fail(h, BRISK_HIP_EINVAL, "insert_records_hist: the histogram slices count " + std::to_string(h->h_small[4]) +
+                                                                        " records, " + std::to_string(n_records) + " were handed over");
+    return insert_records_impl(h, d_records, n_records, true);
 }
 
 static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint32_t* d_tags, uint64_t n_records, uint64_t* d_out, uint32_t* d_tags_out,
@@ -1197,14 +1247,17 @@ static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint3
     int rc;
     const u32 grid = std::min<u32>(ROUTE_BLOCKS, nblocks(n_records, 256));
     const u64 chunk = ((n_records + grid - 1) / grid + 255) / 256 * 256;  // records per block, whole 256-record tiles
-    if ((rc = ensure(h, h->route_buf, (size_t)grid * no * 4))) return rc;
-    u32* d_block = (u32*)h->route_buf.p;
-    HIPCHK(h, hipMemsetAsync(h->d_hist, 0, ((u64)no + 1) * 8, h->stream));
+    // owner histogram and offsets live in route_buf: d_hist may hold the scan's partition histogram (export_hist)
+    if ((rc = ensure(h, h->route_buf, (size_t)(no + 1) * 12 + (size_t)grid * no * 4))) return rc;
+    unsigned long long* d_ohist = (unsigned long long*)h->route_buf.p;
+    u32* d_ooff = (u32*)(d_ohist + no + 1);
+    u32* d_block = d_ooff + no + 1;
+    HIPCHK(h, hipMemsetAsync(d_ohist, 0, ((u64)no + 1) * 8, h->stream));
     {
         ProfScope ps(h, S_HIST);
-        hipLaunchKernelGGL(k_owner_hist, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, h->d_hist);
+        hipLaunchKernelGGL(k_owner_hist, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_ohist);
         if (int lrc = launch_check(h, "k_owner_hist")) return lrc;
-        hipLaunchKernelGGL(k_owner_offsets, dim3(1), dim3(ROUTE_MAX_OWNERS), 0, h->stream, no, grid, h->d_hist, d_block, h->d_off);
+        hipLaunchKernelGGL(k_owner_offsets, dim3(1), dim3(ROUTE_MAX_OWNERS), 0, h->stream, no, grid, d_ohist, d_block, d_ooff);
         if (int lrc = launch_check(h, "k_owner_offsets")) return lrc;
     }
     {
@@ -1213,7 +1266,7 @@ static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint3
         if ((rc = launch_check(h, "k_owner_scatter"))) return rc;
     }
     std::vector<u32> off(no + 1);
-    HIPCHK(h, hipMemcpyAsync(off.data(), h->d_off, ((u64)no + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(off.data(), d_ooff, ((u64)no + 1) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (u32 i = 0; i < no; i++) counts[i] = off[i + 1] - off[i];
     return BRISK_HIP_OK;

@@ -1068,6 +1068,22 @@ __global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64*
         }
     }
 }
+// an owner's histogram = the sum of the slices the scanning ranks sent for its partition range
+__global__ void __launch_bounds__(256) k_sum_slices(const unsigned long long* __restrict__ slices, u32 n_slices, u64 len, unsigned long long* __restrict__ hist_at_range,
+                                                    unsigned long long* __restrict__ n_rec_total) {
+    __shared__ unsigned long long s_sum[4];
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long acc = 0;
+    if (i < len) {
+        for (u32 sidx = 0; sidx < n_slices; sidx++) acc += slices[(u64)sidx * len + i];
+        hist_at_range[i] = acc;
+    }
+    unsigned long long recs = acc & 0xffffffffull;
+    for (int o = 32; o > 0; o >>= 1) recs += __shfl_down(recs, o, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = recs;
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3])) atomicAdd(n_rec_total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
 __global__ void __launch_bounds__(256) k_iota(u32* __restrict__ out, u64 n) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (u32)i;

@@ -80,7 +80,7 @@ class ShardedCounter:
         self.ix = brisk_amd.BriskHip(k, m, b, device=device, stream=stream.cuda_stream, owner_rank=rank, n_owners=world,
                                      part_bits=part_bits)
         self.W = self.ix.record_words
-        self._rec = self._out = self._inbox = None
+        self._rec = self._out = self._inbox = self._hist = None
         self._cap = 0
 
     def count_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> None:
@@ -104,9 +104,16 @@ class ShardedCounter:
                     cap = ix.scan_bound(d_starts.data_ptr(), n_reads)
             self._cap = cap
             counts = ix.route_records(self._rec.data_ptr(), n_rec, self._out.data_ptr())
+            # the scan counted its records per partition: each owner gets the slice of its range and adds the
+            # slices up instead of counting the records it receives again (226 M random atomics per 50 M reads)
+            n_parts = 1 << ix.layout["part_bits"]
+            if self._hist is None:
+                self._hist = torch.empty(n_parts, dtype=torch.int64, device=self.dev)
+            lens = [int(v) for v in ix.export_hist(self._hist.data_ptr())]
             self._inbox, recv_counts = exchange_records(self._out, counts, W, self.group, self._inbox)
+            slices, _ = exchange_records(self._hist, lens, 1, self.group, None)  # every rank sends me my range: world equal slices
             self.stream.synchronize()
-            ix.insert_records(self._inbox.data_ptr(), sum(recv_counts))
+            ix.insert_records_hist(self._inbox.data_ptr(), sum(recv_counts), slices.data_ptr(), self.world)
 
     def stats(self) -> dict:
         """Brisk::stats of the whole sharded index: buckets, super-k-mers, entries and memory add up over the

@@ -101,7 +101,7 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_insert_records", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
+    "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
@@ -137,6 +137,8 @@ def load() -> C.CDLL:
     L.brisk_hip_scan_bound.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.brisk_hip_route_records.argtypes = [vp, vp, u64, vp, _u64p]
     L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
+    L.brisk_hip_export_hist.argtypes = [vp, vp, _u64p]
+    L.brisk_hip_insert_records_hist.argtypes = [vp, vp, u64, vp, u32]
     L.brisk_hip_scan_query.argtypes = [vp, vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.brisk_hip_route_tagged.argtypes = [vp, vp, vp, u64, vp, vp, _u64p]
     L.brisk_hip_query_records.argtypes = [vp, vp, u64, vp]
@@ -317,6 +319,15 @@ class BriskHip:
 
     def insert_records(self, d_records: int, n: int):
         self._chk(self.L.brisk_hip_insert_records(self.h, d_records, n))
+
+    def export_hist(self, d_hist_out: int) -> np.ndarray:
+        """copy the last scan's per-partition histogram (2^part_bits u64) to d_hist_out; returns the slice length per owner"""
+        lens = np.zeros(max(self.layout["n_owners"], 1), np.uint64)
+        self._chk(self.L.brisk_hip_export_hist(self.h, d_hist_out, lens))
+        return lens
+
+    def insert_records_hist(self, d_records: int, n: int, d_hist_slices: int, n_slices: int):
+        self._chk(self.L.brisk_hip_insert_records_hist(self.h, d_records, n, d_hist_slices, n_slices))
 
     def scan_query(self, d_packed: int, d_starts: int, n_reads: int, d_records: int, d_tags: int, cap: int) -> int:
         """query-mode scan: records + the index of the read each came from (u32)"""

@@ -174,6 +174,16 @@ int brisk_hip_route_records(brisk_hip_index *h, const uint64_t *d_records, uint6
                             uint64_t *d_out, uint64_t *counts);
 /* insert records whose buckets this index owns */
 int brisk_hip_insert_records(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records);
+/* The scan of a sharded index also counts its records per bucket-range partition (records in the low,
+ * k-mer instances in the high 32 bits).  export_hist copies that histogram (2^part_bits u64, partition
+ * order = owner order) to d_hist_out right after brisk_hip_scan_packed; partitions_per_owner[n_owners]
+ * (HOST) receives the length of each owner's slice, so that the slices can travel with the records.
+ * insert_records_hist is insert_records for an owner that received one such slice of ITS range from
+ * each scanning rank (n_slices slices of equal length, back to back): it adds them up instead of
+ * counting the received records again. */
+int brisk_hip_export_hist(brisk_hip_index *h, uint64_t *d_hist_out, uint64_t *partitions_per_owner);
+int brisk_hip_insert_records_hist(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records,
+                                  const uint64_t *d_hist_slices, uint32_t n_slices);
 /* The query path cut at the same boundary.  scan_query = the scan as query_sequence runs it (a read's
  * enumeration stops at the first super-k-mer after the first whose returned minimizer is 0,
  * apps/counter.cpp:304-306); d_tags[i] = index of the read record i came from.  route_tagged = route_records

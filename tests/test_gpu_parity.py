@@ -205,6 +205,8 @@ def test_bucket_range_sharding_two_owners(B, O):
         # each "rank" scans half of the reads
         half = len(reads) // 2
         inbox = [[], []]
+        hist_slices = [[], []]
+        n_parts = 1 << ix0.layout["part_bits"]
         for r, (lo, hi) in enumerate(((0, half), (half, len(reads)))):
             ix = owners[r]
             st = d_starts[lo:hi + 1].contiguous()
@@ -214,16 +216,25 @@ def test_bucket_range_sharding_two_owners(B, O):
             torch.cuda.synchronize()
             n_rec = ix.scan_packed(d_packed.data_ptr(), st.data_ptr(), hi - lo, d_rec.data_ptr(), bound)
             counts = ix.route_records(d_rec.data_ptr(), n_rec, d_out.data_ptr())
+            d_hist = torch.zeros(n_parts, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            lens = ix.export_hist(d_hist.data_ptr())  # the scan's per-partition counts travel with the records
             ix.sync()
-            assert int(counts.sum()) == n_rec
+            assert int(counts.sum()) == n_rec and int(lens.sum()) == n_parts
             o0 = int(counts[0])
             inbox[0].append(d_out[: o0 * W].clone())
             inbox[1].append(d_out[o0 * W: n_rec * W].clone())
+            hist_slices[0].append(d_hist[: int(lens[0])].clone())
+            hist_slices[1].append(d_hist[int(lens[0]):].clone())
         lines, nk, nb = [], 0, 0
         for r in range(2):
             recv = torch.cat(inbox[r])
+            slices = torch.cat(hist_slices[r])
             torch.cuda.synchronize()
-            owners[r].insert_records(recv.data_ptr(), recv.numel() // W)
+            if k == 63:  # the owner adds the scanners' histogram slices up ...
+                owners[r].insert_records_hist(recv.data_ptr(), recv.numel() // W, slices.data_ptr(), 2)
+            else:        # ... or counts what it received itself
+                owners[r].insert_records(recv.data_ptr(), recv.numel() // W)
             st = owners[r].stats()
             nk += st["nb_kmers"]
             nb += st["nb_buckets"]
