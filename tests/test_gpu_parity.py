@@ -89,7 +89,7 @@ SPECIAL = ["A" * 150, "C" * 150, "G" * 150, "T" * 150, "AC" * 75, "ACG" * 50, "A
            "A" * 70 + "ACGTTGCA" * 10, "acgt" * 40, "ACGTTGCATGCA" * 13]
 
 
-@pytest.mark.parametrize("k,m,b", CONFIGS + [(33, 11, 7), (47, 15, 10), (21, 7, 3), (63, 31, 12), (41, 21, 5), (63, 21, 4)])
+@pytest.mark.parametrize("k,m,b", CONFIGS + [(33, 11, 7), (47, 15, 10), (21, 7, 3), (63, 31, 12), (41, 21, 5), (63, 21, 4), (32, 13, 6), (34, 21, 9), (31, 11, 11)])
 def test_random_and_degenerate_reads_vs_oracle(B, O, k, m, b):
     rng = random.Random(k * 1000 + m * 10 + b)
     reads = _random_reads(rng, 500, 5000) + SPECIAL
