@@ -1084,6 +1084,10 @@ __global__ void __launch_bounds__(256) k_sum_slices(const unsigned long long* __
     __syncthreads();
     if (threadIdx.x == 0 && (s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3])) atomicAdd(n_rec_total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
+__global__ void __launch_bounds__(256) k_rebase(u64* __restrict__ v, u64 n, u64 base) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] -= base;
+}
 __global__ void __launch_bounds__(256) k_iota(u32* __restrict__ out, u64 n) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (u32)i;

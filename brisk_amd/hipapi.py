@@ -37,7 +37,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     srcs.append(os.path.join(ROOT, "include", "brisk_hip.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fvisibility=hidden",
            "-Wno-unused-value", "-o", out, srcs[0]]
     if verbose:
         print(" ".join(cmd))

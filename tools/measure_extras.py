@@ -30,6 +30,7 @@ def main():
     with B.BriskHip(k, m, b) as ix:
         ix.insert_flat(flat, offs)  # warm-up: allocations, arena mapping
         ix.clear()
+        ix.sync()
         t0 = time.perf_counter()
         ix.insert_flat(flat, offs)
         ix.sync()
