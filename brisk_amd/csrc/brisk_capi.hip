@@ -597,8 +597,9 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
         *n_rec_out = 0;
         return BRISK_HIP_OK;
     }
-    // first try: a few records per short read, one per ~(w+2)/2 k-mers of a long one (twice that, for slack)
-    u64 cap = std::min<u64>(bound, n_reads * 8 + 4 * in_long / (h->P.w + 2) + 4096);
+    // first try: a record per ~(w+2)/2 k-mers (a quarter more, for slack) and the one that ends every read
+    (void)in_long;
+    u64 cap = std::min<u64>(bound, 5 * bound / (2 * (h->P.w + 2)) + 2 * n_reads + 4096);
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = ensure(h, h->staging, cap * h->P.stride * 8))) return rc;
         u32* tags = nullptr;

@@ -1377,9 +1377,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 const u32 x0 = wave_incl_scan(raw_n, lane);
                 // First try every available record: identical records (the same super-k-mer seen in
                 // several reads) collapse into one with a multiplicity, so far more raw instances fit.
-                // If the collapsed chunk is still too big, fall back to the raw-count prefix.
+                // If the collapsed chunk is still too big, shrink to the prefix whose collapsed count fits (counted
+                // again on its own it can come out a little higher, once the first copy of a record lies beyond
+                // it: hence the loop), at the latest to the raw-count prefix, which always fits.
+                const u32 rawfit = (u32)__popcll(__ballot(lane < avail && x0 <= WI_MAX_INST));  // >= 1; a prefix: x0 is monotone
                 u32 nrec = avail, my_n = 0, x = 0, ninst = 0;
-                for (int attempt = 0; attempt < 2; attempt++) {
+                for (int attempt = 0;; attempt++) {
                     s_rtab[lane] = EMPTY_SLOT;
                     s_rtab[lane + 64] = EMPTY_SLOT;
                     s_rmult[lane] = 1;
@@ -1409,7 +1412,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                     x = wave_incl_scan(my_n, lane);
                     ninst = __shfl(x, 63, 64);
                     if (ninst <= WI_MAX_INST) break;
-                    nrec = (u32)__popcll(__ballot(lane < avail && x0 <= WI_MAX_INST));  // >= 1; a prefix: x0 is monotone
+                    const u32 fit = (u32)__popcll(__ballot(lane < nrec && x <= WI_MAX_INST));  // x is monotone too
+                    nrec = (attempt >= 2 || fit <= rawfit) ? rawfit : min(fit, nrec - 1);
                     wave_sync();
                 }
                 const u32 raw_inst = __shfl(x0, nrec - 1, 64);
