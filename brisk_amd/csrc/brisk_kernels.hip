@@ -1470,19 +1470,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 // scope; __threadfence() would write back and invalidate the XCD's whole L2), and waiting
                 // for them here rather than at the end of the last chunk hides them behind phases 0 and 1.
                 if (rc != d.r_begin) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                for (u32 e = lane; e < n_exist; e += 64) {
-                    const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
-                    u32 h = hash_key32(key) & (tsize - 1);
-                    for (;;) {
-                        const u32 v = s_tab[h];
-                        if (v == EMPTY_SLOT) break;
-                        const u32 i = v & WI_IDX_MASK;
-                        if (s_key[2 * i] == key.lo && s_key[2 * i + 1] == key.hi) {
-                            ix.counts[off + e] = (uint8_t)(ix.counts[off + e] + ((v & ~MATCHED_BIT) >> WI_CNT_SHIFT));
-                            s_tab[h] = v | MATCHED_BIT;
-                            break;
+                // Four strides of entries at a time: their key and count loads are in flight together (a big partition
+                // of a hot bucket streams thousands of entries per chunk; one dependent load per stride was most
+                // of this kernel's time at k31/b11).
+                for (u32 e0 = 0; e0 < n_exist; e0 += 4 * 64) {
+                    u64 klo[4], khi[4];
+                    uint8_t cnt[4];
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 e = e0 + q * 64 + lane;
+                        const unsigned long long at = off + (e < n_exist ? e : 0);
+                        klo[q] = ix.keys[2 * at];
+                        khi[q] = ix.keys[2 * at + 1];
+                        cnt[q] = ix.counts[at];
+                    }
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 e = e0 + q * 64 + lane;
+                        if (e >= n_exist) continue;
+                        u32 h = hash_key32(mk128(klo[q], khi[q])) & (tsize - 1);
+                        for (;;) {
+                            const u32 v = s_tab[h];
+                            if (v == EMPTY_SLOT) break;
+                            const u32 i = v & WI_IDX_MASK;
+                            if (s_key[2 * i] == klo[q] && s_key[2 * i + 1] == khi[q]) {
+                                ix.counts[off + e] = (uint8_t)(cnt[q] + ((v & ~MATCHED_BIT) >> WI_CNT_SHIFT));
+                                s_tab[h] = v | MATCHED_BIT;
+                                break;
+                            }
+                            h = (h + 1) & (tsize - 1);
                         }
-                        h = (h + 1) & (tsize - 1);
                     }
                 }
                 wave_sync();
