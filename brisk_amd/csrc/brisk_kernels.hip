@@ -1418,7 +1418,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 }
                 const u32 raw_inst = __shfl(x0, nrec - 1, 64);
                 u32 tsize = 128;
-                while (tsize < ninst + (ninst >> 1) && tsize < WI_TABLE) tsize <<= 1;
+                while (tsize < 2 * ninst && tsize < WI_TABLE) tsize <<= 1;
                 s_pref[lane + 1] = x;
                 if (lane == 0) s_pref[0] = 0;
 #pragma unroll

@@ -489,6 +489,34 @@ def test_checksum_matches_oracle_digest(B, O):
             assert ix.checksum() == want
 
 
+def test_large_host_input_goes_through_the_threaded_upload(B):
+    """Host ASCII above 64 MiB is uploaded by several threads through pinned buffers and packed chunk by chunk;
+    the index must equal the one built from the same bases packed in one piece on the device."""
+    import torch
+    rng = np.random.default_rng(5)
+    L, n = 150, 600_000
+    G = n * L // 15
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, G, dtype=np.uint8)]
+    starts = rng.integers(0, G - L + 1, n)
+    flat = genome[(starts[:, None] + np.arange(L)).ravel()].copy()
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    assert flat.nbytes > 4 * (16 << 20)
+    k, m, b = 63, 21, 14
+    with B.BriskHip(k, m, b) as ix:
+        ix.insert_flat(flat, offs)
+        via_host = ix.checksum()
+    d_bases = torch.from_numpy(flat).cuda()
+    d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    with B.BriskHip(k, m, b) as ix:
+        ix.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n)
+        via_device = ix.checksum()
+        assert via_device[1] == n * (L - k + 1)
+    assert via_host == via_device
+
+
 def test_full_size_properties_config2_and_3(B):
     """BASELINE configs #2' (10M reads, k31 m11 b11: b=14 of config #2 is invalid in the reference, F1)
     and #3 (50M reads, k63 m21 b14) at full size, through size-independent properties: the result does not
