@@ -429,7 +429,7 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     } else {
         const u32 bt = h->scan_waves * 64;
         const dim3 grid(nblocks(n_items, bt)), block(bt);
-        // instantiations: chunk-table count nch = ceil((m-1)/4) (5: m 18..21, 3: m 10..13, else generic) x mode x
+        // instantiations: chunk-table count nch = ceil((m-1)/4) (5: m 18..21, 4: m 14..17, 3: m 10..13, else generic) x mode x
         // {k and m compile-time for the two common parameter sets, or from P}
 #define LAUNCH_SCAN2(NCH, MODE, KK, MM) \
     hipLaunchKernelGGL((k_scan2<NCH, MODE, KK, MM>), grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, cc)
@@ -441,8 +441,10 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     }
         const u32 k = h->P.k, m = h->P.m;
         if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(5, 63, 21)
+        else if (k == 31 && m == 15) LAUNCH_SCAN2_MODES(4, 31, 15)  // the reference's default parameters (apps/counter.cpp:355)
         else if (k == 31 && m == 11) LAUNCH_SCAN2_MODES(3, 31, 11)
         else if (h->scfg.nch == 5) LAUNCH_SCAN2_MODES(5, 0, 0)
+        else if (h->scfg.nch == 4) LAUNCH_SCAN2_MODES(4, 0, 0)
         else if (h->scfg.nch == 3) LAUNCH_SCAN2_MODES(3, 0, 0)
         else LAUNCH_SCAN2_MODES(0, 0, 0)
 #undef LAUNCH_SCAN2_MODES
@@ -934,7 +936,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             if (h->scan_lds > lds_attr) {
                 lds_attr = h->scan_lds;
 #define SCAN2_FNS(NCH, KK, MM) (const void*)k_scan2<NCH, 0, KK, MM>, (const void*)k_scan2<NCH, 1, KK, MM>, (const void*)k_scan2<NCH, 2, KK, MM>
-                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(5, 0, 0), SCAN2_FNS(3, 31, 11), SCAN2_FNS(5, 63, 21)};
+                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(5, 0, 0), SCAN2_FNS(3, 31, 11), SCAN2_FNS(4, 31, 15), SCAN2_FNS(5, 63, 21)};
 #undef SCAN2_FNS
                 for (const void* fn : fns) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
             }
