@@ -13,6 +13,7 @@
 
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -49,25 +50,24 @@ class FastaReader {
         const size_t before = out.size();
         while (out.flat.size() < max_bases) {
             if (pos_ == len_ && !refill()) break;
-            const char c = buf_[pos_++];
+            // one line (or what the buffer holds of it) per turn: memchr for its end, whole runs of bases appended at once
+            const char* p = &buf_[pos_];
+            const char* end = &buf_[0] + len_;
             if (at_line_start_) {
                 at_line_start_ = false;
-                if (c == '>' && !in_header_) {  // next record: close the running sequence
+                if (*p == '>' && !in_header_) {  // next record: close the running sequence
                     close_run(out);
                     in_header_ = true;
                 }
             }
-            if (c == '\n') {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* stop = nl ? nl : end;
+            if (!in_header_) append_bases(out, p, stop);
+            pos_ = (size_t)(stop - &buf_[0]);
+            if (nl) {
+                pos_++;
                 at_line_start_ = true;
                 in_header_ = false;  // the first line of a record is its header
-                continue;
-            }
-            if (in_header_) continue;
-            const char u = (char)(c & ~0x20);
-            if (u == 'A' || u == 'C' || u == 'G' || u == 'T') {
-                out.flat.push_back(u);
-            } else {
-                close_run(out);
             }
         }
         if (eof_ && pos_ == len_) close_run(out);
@@ -78,6 +78,30 @@ class FastaReader {
   private:
     void close_run(FastaBatch& out) {
         if (out.flat.size() > out.offs.back()) out.offs.push_back(out.flat.size());
+    }
+    // [p, stop) holds no newline: maximal runs of [ACGTacgt] are appended upper-cased, anything else closes the run.
+    // One pass: room for the whole stretch is made first, a 256-entry table maps a byte to its upper-case base or 0.
+    struct BaseTable {
+        unsigned char t[256];
+        BaseTable() {
+            std::memset(t, 0, sizeof t);
+            for (const char* c = "ACGT"; *c; c++) t[(unsigned char)*c] = t[(unsigned char)(*c | 0x20)] = (unsigned char)*c;
+        }
+    };
+    void append_bases(FastaBatch& out, const char* p, const char* stop) {
+        static const BaseTable tab;
+        size_t o = out.flat.size();
+        out.flat.resize(o + (size_t)(stop - p));
+        char* d = &out.flat[0];
+        for (; p < stop; p++) {
+            const unsigned char u = tab.t[(unsigned char)*p];
+            if (u) {
+                d[o++] = (char)u;
+            } else if (o > out.offs.back()) {
+                out.offs.push_back(o);
+            }
+        }
+        out.flat.resize(o);
     }
     bool refill() {
         if (eof_) return false;
@@ -126,9 +150,10 @@ class FastaBatcher {
   private:
     void run() {
         try {
+            FastaBatch b;  // buffers circulate: what next() swapped back into the slot is filled again (no fresh pages per batch)
             for (;;) {
-                FastaBatch b;
                 b.clear();
+                if (b.flat.capacity() < batch_bases_) b.flat.reserve(batch_bases_ + (batch_bases_ >> 4) + (1 << 20));
                 // a batch may end inside a sequence only at the end of the file: keep reading until a run closes
                 bool more = reader_.fill(b, batch_bases_);
                 while (more && !reader_.done() && b.flat.size() > b.offs.back()) more = reader_.fill(b, b.flat.size() + (1 << 16));
