@@ -56,6 +56,31 @@ def exchange_records(send: torch.Tensor, send_counts, words: int, group=None,
     return inbox, recv_counts
 
 
+def exchange_counts(send_counts, device, group=None) -> List[int]:
+    """the small all-to-all that goes first: how many records every rank is about to send me"""
+    sc = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=device)
+    if sc.is_cuda and dist.get_backend(group) == "gloo":
+        sc = sc.cpu()
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    return [int(v) for v in rc.cpu().tolist()]
+
+
+def exchange_payload_async(send: torch.Tensor, send_counts, recv_counts, words: int, out: torch.Tensor, out_offset: int, group=None):
+    """The payload all-to-all into out[out_offset*words : ...], not waited for: returns a work handle (None when the
+    transfer is already complete, as on the gloo rehearsal path).  `send` and `out` must stay untouched until wait()."""
+    n_in, n_out = int(sum(recv_counts)), int(sum(int(c) for c in send_counts))
+    view = out[out_offset * words: (out_offset + n_in) * words]
+    if send.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal: through host memory, synchronously
+        host = torch.empty(max(n_in, 1) * words, dtype=send.dtype)
+        dist.all_to_all_single(host[: n_in * words], send[: n_out * words].cpu(), output_split_sizes=[c * words for c in recv_counts],
+                               input_split_sizes=[int(c) * words for c in send_counts], group=group)
+        view.copy_(host[: n_in * words])
+        return None
+    return dist.all_to_all_single(view, send[: n_out * words], output_split_sizes=[c * words for c in recv_counts],
+                                  input_split_sizes=[int(c) * words for c in send_counts], group=group, async_op=True)
+
+
 def return_sums(sums: torch.Tensor, recv_counts, send_counts, tags: torch.Tensor, n_reads: int, group=None) -> torch.Tensor:
     """Return trip of a sharded get.  `sums` (int64, one per record this rank answered, in the order the
     records arrived: grouped by source rank) goes back to the ranks the records came from; what comes
@@ -84,36 +109,74 @@ class ShardedCounter:
         self._cap = 0
 
     def count_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> None:
+        """Count this rank's reads into the sharded index.  The reads go in two halves so that the all-to-all of the
+        first half's records runs while the second half is scanned; the owner inserts everything it received at once."""
         ix, W = self.ix, self.W
         if self.world == 1:
             ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
             return
         import brisk_amd
+        halves = [(0, n_reads // 2), (n_reads // 2, n_reads)] if n_reads >= 2 else [(0, n_reads)]
+        n_parts = 1 << ix.layout["part_bits"]
         with torch.cuda.stream(self.stream):
             cap = self._cap or (n_reads * 6 + 4096)
-            while True:
-                if self._rec is None or self._rec.numel() < cap * W:
-                    self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
-                    self._out = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
-                try:
-                    n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, self._rec.data_ptr(), cap)
-                    break
-                except brisk_amd.BriskHipError as e:
-                    if e.code != brisk_amd.hipapi.ECAPACITY:
-                        raise
-                    cap = ix.scan_bound(d_starts.data_ptr(), n_reads)
-            self._cap = cap
-            counts = ix.route_records(self._rec.data_ptr(), n_rec, self._out.data_ptr())
-            # the scan counted its records per partition: each owner gets the slice of its range and adds the
-            # slices up instead of counting the records it receives again (226 M random atomics per 50 M reads)
-            n_parts = 1 << ix.layout["part_bits"]
+            if self._rec is None or self._rec.numel() < cap * W:
+                self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
+                self._out = [torch.empty(cap * W, dtype=torch.int64, device=self.dev) for _ in halves]
+                self._inbox = torch.empty((cap + cap // 4) * W, dtype=torch.int64, device=self.dev)
             if self._hist is None:
-                self._hist = torch.empty(n_parts, dtype=torch.int64, device=self.dev)
-            lens = [int(v) for v in ix.export_hist(self._hist.data_ptr())]
-            self._inbox, recv_counts = exchange_records(self._out, counts, W, self.group, self._inbox)
-            slices, _ = exchange_records(self._hist, lens, 1, self.group, None)  # every rank sends me my range: world equal slices
+                self._hist = [torch.empty(n_parts, dtype=torch.int64, device=self.dev) for _ in halves]
+            slices = None
+            works, n_in_total, n_slices = [], 0, 0
+            for hi_, (lo, hi) in enumerate(halves):
+                starts_ptr = d_starts.data_ptr() + lo * 8
+                while True:
+                    try:
+                        n_rec = ix.scan_packed(d_packed.data_ptr(), starts_ptr, hi - lo, self._rec.data_ptr(), self._rec.numel() // W)
+                        break
+                    except brisk_amd.BriskHipError as e:
+                        if e.code != brisk_amd.hipapi.ECAPACITY:
+                            raise
+                        for w in works:  # the buffers are about to be replaced: nothing may still be reading them
+                            if w is not None:
+                                w.wait()
+                        works = []
+                        self.stream.synchronize()
+                        cap = max(cap * 2, ix.scan_bound(starts_ptr, hi - lo))
+                        self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
+                        new_out = [torch.empty(cap * W, dtype=torch.int64, device=self.dev) for _ in halves]
+                        for a_, b_ in zip(new_out, self._out):
+                            a_[: b_.numel()].copy_(b_)
+                        self._out = new_out
+                out = self._out[hi_]
+                counts = ix.route_records(self._rec.data_ptr(), n_rec, out.data_ptr())
+                # the scan counted its records per partition: each owner gets the slice of its range and adds the
+                # slices up instead of counting the records it receives again (226 M random atomics per 50 M reads)
+                lens = [int(v) for v in ix.export_hist(self._hist[hi_].data_ptr())]
+                recv_counts = exchange_counts(counts, self.dev, self.group)
+                n_in = sum(recv_counts)
+                if (n_in_total + n_in) * W > self._inbox.numel():  # skewed ownership: make room (what arrived is kept)
+                    for w in works:
+                        if w is not None:
+                            w.wait()
+                    works = []
+                    self.stream.synchronize()
+                    bigger = torch.empty((n_in_total + n_in) * W * 2, dtype=torch.int64, device=self.dev)
+                    bigger[: n_in_total * W].copy_(self._inbox[: n_in_total * W])
+                    self._inbox = bigger
+                works.append(exchange_payload_async(out, counts, recv_counts, W, self._inbox, n_in_total, self.group))
+                my_len = lens[self.rank]
+                if slices is None:
+                    slices = torch.empty(len(halves) * self.world * my_len, dtype=torch.int64, device=self.dev)
+                works.append(exchange_payload_async(self._hist[hi_], lens, [my_len] * self.world, 1, slices, n_slices * my_len, self.group))
+                n_in_total += n_in
+                n_slices += self.world
+            self._cap = cap
+            for w in works:
+                if w is not None:
+                    w.wait()
             self.stream.synchronize()
-            ix.insert_records_hist(self._inbox.data_ptr(), sum(recv_counts), slices.data_ptr(), self.world)
+            ix.insert_records_hist(self._inbox.data_ptr(), n_in_total, slices.data_ptr(), n_slices)
 
     def stats(self) -> dict:
         """Brisk::stats of the whole sharded index: buckets, super-k-mers, entries and memory add up over the
