@@ -6,6 +6,7 @@ import hashlib
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -13,6 +14,7 @@ import brisk_amd
 from conftest import GOLDEN, load_golden
 
 APPS = os.path.join(os.path.dirname(brisk_amd.__file__), "apps")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(brisk_amd.__file__)))
 
 
 def test_facade_compiles_and_counter_cpp_links_unchanged():
@@ -80,3 +82,26 @@ def test_reference_counter_cpp_runs_on_the_gpu_index():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "All counts are correct !" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
     assert re.search(r"nb kmers: 6,105", out.stdout) and re.search(r"^237 bucket used", out.stdout, re.M)
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the keys the driver reads, a roofline and a cpu_baseline object, and its
+    own size-independent verification of what it built."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "300000", "--steps", "1", "--warmup", "1", "--cpu-sample-reads", "20000"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["verify"]["every_kmer_counted_once"] is True
