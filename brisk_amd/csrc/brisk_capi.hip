@@ -869,9 +869,15 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     P.kb = k - b;
     P.nw = (2 * (2 * k - m - b) + 63) / 64;
     P.stride = P.nw + 1;
-    P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(2u * b, 24u);
-    P.shift = 2 * b - P.part_bits;
-    // the entry key [bucket low bits | compacted | idx'] must fit 128 bits
+    // Partitions: by default up to 2^24 of them whatever b is -- a small b leaves few buckets, so records are routed
+    // by the bucket id plus ext_bits more bits of the same hashed minimizer (at most what it has: 2m - 2b, and what
+    // the record header has room for).  An explicit part_bits keeps plain bucket ranges.
+    P.ext_bits = 0;
+    if (!o.part_bits && 2u * b < 24u) P.ext_bits = std::min<u32>(std::min<u32>(24u - 2u * b, 2u * (m - b)), 16u);
+    const u32 rbits = 2u * b + P.ext_bits;
+    P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(rbits, 24u);
+    P.shift = rbits - P.part_bits;
+    // the entry key [routing id low bits | compacted | idx'] must fit 128 bits
     while (P.shift + 2 * P.kb + 6 > 128 && P.shift > 0) { P.shift--; P.part_bits++; }
     if (P.shift + 2 * P.kb + 6 > 128 || P.part_bits > 30) {
         delete h;
@@ -1060,6 +1066,7 @@ BRISK_API int brisk_hip_get_layout(const brisk_hip_index* h, brisk_hip_layout* o
     out->allocated_bytes = (2 * P.k - P.m - P.b + 3) / 4;  // parameters.hpp:31
     out->record_words = P.stride;
     out->part_bits = P.part_bits;
+    out->ext_bits = P.ext_bits;
     out->n_owners = P.n_owners;
     out->owner_rank = P.owner_rank;
     return BRISK_HIP_OK;

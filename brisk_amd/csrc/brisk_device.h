@@ -20,18 +20,22 @@ struct BriskParams {
     u32 nw;          // u64 words holding a compacted super-k-mer (2k-m-b nts)
     u32 stride;      // nw + 1: record words, last one is the header
     u32 part_bits;   // log2(#partitions)
-    u32 shift;       // 2b - part_bits: bucket bits kept inside an entry key
+    u32 ext_bits;    // minimizer-hash bits beyond the bucket's that route a record (0 once 2b >= 24): rid = bucket << ext_bits | extra
+    u32 shift;       // 2b + ext_bits - part_bits: routing-id bits kept inside an entry key
     u32 n_owners, owner_rank;
     u64 m_mask;      // 2m ones
     u64 bucket_mask; // 2b ones
 };
 
-// record header word: [0,32) bucket id, [32,40) n k-mers, [40,48) idx' of k-mer 0,
+// record header word: [0,32) routing id, [32,40) n k-mers, [40,48) idx' of k-mer 0,
 // [48,64) zero.  idx' = minimizer_idx + suff_reduc (SuperKmerLight.hpp:98).
-__device__ __forceinline__ u64 rec_header(u32 bucket, u32 n, u32 idx0p) {
-    return (u64)bucket | ((u64)n << 32) | ((u64)idx0p << 40);
+// Routing id = the bucket id (Brisk.hpp:135-137) followed by ext_bits more bits of the same hashed minimizer:
+// every k-mer of a super-k-mer shares them, so records can be spread over up to 2^24 partitions however small b is
+// (a partition is then a slice of a bucket instead of a range of buckets).  ext_bits == 0: the bucket id itself.
+__device__ __forceinline__ u64 rec_header(u32 rid, u32 n, u32 idx0p) {
+    return (u64)rid | ((u64)n << 32) | ((u64)idx0p << 40);
 }
-__device__ __forceinline__ u32 hdr_bucket(u64 h) { return (u32)h; }
+__device__ __forceinline__ u32 hdr_bucket(u64 h) { return (u32)h; }  // the routing id
 __device__ __forceinline__ u32 hdr_n(u64 h) { return (u32)(h >> 32) & 0xffu; }
 __device__ __forceinline__ u32 hdr_idx0(u64 h) { return (u32)(h >> 40) & 0xffu; }
 
@@ -232,7 +236,15 @@ __device__ __forceinline__ u64 order_key(u64 x, u32 m, u64 M, const double* coef
 }
 
 // ---------------------------------------------------------------------------
-// entry key inside a partition: [bucket low `shift` bits | compacted k-mer (2kb) | idx' (6)]
+// routing id of a hashed minimizer h (2m bits): [bucket (2b bits, Brisk.hpp:135-137) | ext_bits of what is left of h:
+// the 2*suff_reduc bits below the bucket first, then the bits above it]
+__device__ __forceinline__ u32 routing_id(const BriskParams& P, u64 h) {
+    const u32 bucket = (u32)((h >> (2 * P.suff_reduc)) & P.bucket_mask);
+    if (!P.ext_bits) return bucket;
+    const u64 rest = ((h >> (2 * (P.suff_reduc + P.b))) << (2 * P.suff_reduc)) | (h & ((1ull << (2 * P.suff_reduc)) - 1));
+    return (bucket << P.ext_bits) | (u32)(rest & ((1u << P.ext_bits) - 1));
+}
+// entry key inside a partition: [routing id low `shift` bits | compacted k-mer (2kb) | idx' (6)]
 __device__ __forceinline__ u128x make_key(const BriskParams& P, u32 bucket, u128x comp, u32 idxp) {
     u128x key = shl128(comp, 6);
     key.lo |= idxp;
@@ -260,6 +272,7 @@ __device__ __forceinline__ u128x entry_hashed_kmer(const BriskParams& P, u32 par
     const u128x comp = and128(shr128(key, 6), mask128(2 * P.kb));
     u32 bucket = part << P.shift;
     if (P.shift) bucket |= (u32)shr128(key, 2 * P.kb + 6).lo & ((1u << P.shift) - 1);
+    bucket >>= P.ext_bits;  // routing id -> bucket id
     const u128x suffix = and128(comp, mask128(2 * idxp));
     const u128x prefix = shr128(comp, 2 * idxp);
     u128x r = or128(shl128(prefix, 2 * (idxp + P.b)), suffix);

@@ -194,7 +194,7 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
     // of the last one (hash_kmer_minimizer_inplace re-extracts it, Kmers.cpp:191-200)
     const u64 mm = w4_shr(S, 2 * idx_end).w0 & P.m_mask;
     const u64 h = mix2m(mm, P.m_mask);
-    const u32 bucket = (u32)((h >> (2 * P.suff_reduc)) & P.bucket_mask);  // Brisk.hpp:135-137
+    const u32 bucket = routing_id(P, h);  // Brisk.hpp:135-137, plus the extra routing bits
     // replace the minimizer by its hash (replace_slice, Kmers.cpp:149-159)
     const W4 hole = w4_shl(W4{P.m_mask, 0, 0, 0}, 2 * idx_end);
     S = w4_or(w4_andn(S, hole), w4_shl(W4{h, 0, 0, 0}, 2 * idx_end));
@@ -1585,12 +1585,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
             if (P.shift <= 6 && lane < 2) {
                 const u32 mask = lane == 0 ? bm0 : bm1;
                 const u32 nb = 1u << P.shift;  // buckets per partition
-                const u64 first = (u64)part << P.shift;
+                const u64 first = ((u64)part << P.shift) >> P.ext_bits;  // ext_bits > 0 => shift == 0: the one bucket this partition is a slice of
+                // a bit that is already set needs no atomic: with few buckets (small b) every partition of a bucket
+                // would otherwise hit the same word, and same-address atomics serialise device-wide
                 if (mask) {
                     if (nb >= 32) {
-                        if (lane * 32 < nb) atomicOr(&ix.bucket_bits[(first >> 5) + lane], mask);
+                        if (lane * 32 < nb && (ix.bucket_bits[(first >> 5) + lane] & mask) != mask) atomicOr(&ix.bucket_bits[(first >> 5) + lane], mask);
                     } else if (lane == 0) {
-                        atomicOr(&ix.bucket_bits[first >> 5], mask << (first & 31));
+                        const u32 bits = mask << (first & 31);
+                        if ((ix.bucket_bits[first >> 5] & bits) != bits) atomicOr(&ix.bucket_bits[first >> 5], bits);
                     }
                 }
             }
@@ -1826,7 +1829,7 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
     if (idx <= P.w) {
         const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
         const u64 h = mix2m(mm, P.m_mask);
-        const u32 bucket = (u32)((h >> (2 * P.suff_reduc)) & P.bucket_mask);
+        const u32 bucket = routing_id(P, h);
         km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
         const u32 cut = idx + P.suff_reduc;
         const u128x lowm = mask128(2 * cut);
@@ -1862,13 +1865,13 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
 __device__ __forceinline__ u128x key_of_kmer(const BriskParams& P, u128x km, u32 idx, u32* part, u32* bucket_out) {
     const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
     const u64 h = mix2m(mm, P.m_mask);
-    const u32 bucket = (u32)((h >> (2 * P.suff_reduc)) & P.bucket_mask);
+    const u32 bucket = routing_id(P, h);
     km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
     const u32 cut = idx + P.suff_reduc;
     const u128x lowm = mask128(2 * cut);
     const u128x comp = or128(andn128(shr128(km, 2 * P.b), lowm), and128(km, lowm));
     *part = bucket >> P.shift;
-    *bucket_out = bucket;
+    *bucket_out = bucket >> P.ext_bits;  // the bucket id proper (for the occupancy bitmap)
     return make_key(P, bucket, and128(comp, mask128(2 * P.kb)), cut);
 }
 
@@ -1929,7 +1932,7 @@ __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const
                 ix.counts[at] = 0;
                 ix.ids[at] = nid;
                 ix.dir[part] = DirEnt{de.off, de.cnt + 1, de.cap};
-                atomicOr(&ix.bucket_bits[bucket >> 5], 1u << (bucket & 31));
+                if (!(ix.bucket_bits[bucket >> 5] >> (bucket & 31) & 1u)) atomicOr(&ix.bucket_bits[bucket >> 5], 1u << (bucket & 31));
                 out_id[qi] = nid;
                 out_new[qi] = 1;
             }

@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define BRISK_HIP_ABI_VERSION 1
+#define BRISK_HIP_ABI_VERSION 2
 
 enum {
     BRISK_HIP_OK = 0,
@@ -113,6 +113,8 @@ typedef struct brisk_hip_layout {
     uint32_t record_words;      /* u64 words per super-k-mer record (incl. header word) */
     uint32_t part_bits;         /* log2(#partitions) */
     uint32_t n_owners, owner_rank;
+    uint32_t ext_bits;          /* a record's routing id (header bits 0..31) = bucket id << ext_bits | that many more bits of
+                                 * the same hashed minimizer; 0 when 2b >= 24 or part_bits was given: the bucket id itself */
 } brisk_hip_layout;
 int brisk_hip_get_layout(const brisk_hip_index *h, brisk_hip_layout *out);
 

@@ -180,7 +180,8 @@ def test_scan_records_match_oracle_records(B, O):
             n_rec = ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), len(reads), d_rec.data_ptr(), bound)
             ix.sync()
             rec = d_rec.cpu().numpy().view(np.uint64)[: n_rec * W].reshape(n_rec, W)
-        got = [tuple(int(x) for x in r[: W - 1]) + (int(r[W - 1]) & 0xffffffff, (int(r[W - 1]) >> 32) & 0xff, (int(r[W - 1]) >> 40) & 0xff)
+            ext = ix.layout["ext_bits"]  # header bits 0..31: bucket id << ext | extra routing bits of the same minimizer hash
+        got = [tuple(int(x) for x in r[: W - 1]) + ((int(r[W - 1]) & 0xffffffff) >> ext, (int(r[W - 1]) >> 32) & 0xff, (int(r[W - 1]) >> 40) & 0xff)
                for r in rec]
         assert sorted(got) == sorted(want)
 
