@@ -117,7 +117,12 @@ int ensure(brisk_hip_index* h, DevBuf& b, size_t bytes) {
         b.bytes = 0;
     }
     size_t want = bytes + bytes / 8 + 256;
-    HIPCHK(h, hipMalloc(&b.p, want));
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // the failed allocation must not surface later as some kernel's launch error
+        b.p = nullptr;
+        return fail(h, e == hipErrorOutOfMemory ? BRISK_HIP_ENOMEM : BRISK_HIP_EHIP, std::string("device allocation of ") + std::to_string(want >> 20) + " MiB: " + hipGetErrorString(e));
+    }
     b.bytes = want;
     return BRISK_HIP_OK;
 }
@@ -187,7 +192,10 @@ int vm_grow(brisk_hip_index* h, VmBuf& b, size_t bytes) {
         if (b.mapped + add > b.reserved) return fail(h, BRISK_HIP_ENOMEM, "arena: virtual reservation exhausted");
         hipMemGenericAllocationHandle_t hd;
         hipError_t e = hipMemCreate(&hd, add, &prop, 0);
-        if (e != hipSuccess) return fail(h, BRISK_HIP_ENOMEM, std::string("arena growth: hipMemCreate: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, BRISK_HIP_ENOMEM, std::string("arena growth: hipMemCreate: ") + hipGetErrorString(e));
+        }
         e = hipMemMap(b.base + b.mapped, add, 0, hd, 0);
         if (e != hipSuccess) {
             hipMemRelease(hd);
@@ -312,11 +320,12 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
     uint8_t* nc = nullptr;
     u32* ni = nullptr;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMalloc((void**)&nk, ncap * 16));
-    hipError_t e = hipMalloc((void**)&nc, ncap);
+    hipError_t e = hipMalloc((void**)&nk, ncap * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&nc, ncap);
     if (e == hipSuccess && h->entry_ids) e = hipMalloc((void**)&ni, ncap * 4);
     if (e != hipSuccess) {
-        hipFree(nk);
+        (void)hipGetLastError();  // the failed allocation must not surface later as some kernel's launch error
+        if (nk) hipFree(nk);
         if (nc) hipFree(nc);
         return fail(h, BRISK_HIP_ENOMEM, "arena growth: out of device memory");
     }

@@ -1140,7 +1140,9 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
 // workgroup's private arena chunk, so the global cursor sees one atomic per
 // ARENA_CHUNK entries.  nb_kmers / nb_buckets are reductions done at stats() time:
 // the kernel has no same-address global atomics on its data path.
-#define ARENA_CHUNK 32768u
+#ifndef ARENA_CHUNK
+#define ARENA_CHUNK 16384u   // entries a persistent wave takes from the global cursor at a time
+#endif
 // k_insert is bound by each wave's own serial instruction stream (LDS round trips, short dependent
 // chains), so throughput follows the number of resident waves: chunks of 256 instances keep LDS at
 // 10 KB and registers at 128 per wave => 4 waves per SIMD (512-instance chunks: 16 KB, 201 registers,
