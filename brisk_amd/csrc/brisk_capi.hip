@@ -477,7 +477,8 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
     const bool plain = h->scan_v1 || d_ret;
     int rc;
     u32 n_vr = 0;
-    const bool may_chunk = !plain && !query_mode && !d_tags && kmer_bound > SCAN_LONG;
+    // long sequences are chunked in insert mode (no tags) and in query mode (read tags); not in sequence mode (plain)
+    const bool may_chunk = !plain && kmer_bound > SCAN_LONG && (query_mode ? d_tags != nullptr : !d_tags);
     VRead *d_vr = nullptr, *d_rerun = nullptr;
     ChunkState *d_spec = nullptr, *d_truth = nullptr;
     u32 *d_status = nullptr, *d_cursor = nullptr, *d_stop = nullptr;
@@ -520,11 +521,20 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
         HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         const u64 n1 = std::min<u64>(h->h_small[0], cap);
-        if ((rc = ensure(h, h->tags_a, cap * 4))) return rc;
+        u32* d_ctags = d_tags;  // chunk index per record of the chunked launches (query mode: in the caller's tag array, read indices later)
+        u64* d_qret = nullptr;  // query mode: where a record's vector starts | its minimizer is 0 << 63
+        if (!query_mode) {
+            if ((rc = ensure(h, h->tags_a, cap * 4))) return rc;
+            d_ctags = (u32*)h->tags_a.p;
+        } else {
+            if ((rc = ensure(h, h->seq_buf, cap * 8 + cap_vr * 8))) return rc;
+            d_qret = (u64*)h->seq_buf.p;
+        }
         HIPCHK(h, hipMemsetAsync(d_spec, 0, (2 * cap_vr + 1) * sizeof(ChunkState) + 2 * cap_vr * 4, h->stream));  // states, status, cursor
         HIPCHK(h, hipMemsetAsync(d_stop, 0xff, cap_vr * 4, h->stream));
         ScanOut out2 = out;
-        out2.tag = (u32*)h->tags_a.p;
+        out2.tag = d_ctags;
+        out2.ret = d_qret;
         ChunkCtl c2{d_vr, d_spec, d_truth, 0u};
         if ((rc = launch_scan(h, d_packed, d_starts, n_vr, out2, false, false, c2))) return rc;
         HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
@@ -552,7 +562,37 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
         static const bool dbg_chunks = getenv("BRISK_DEBUG_CHUNKS") != nullptr;
         if (dbg_chunks) fprintf(stderr, "[brisk_hip] chunked scan: %u chunks of %u steps, %llu seeded re-scans in %u rounds\n", n_vr, chunk,
                                 (unsigned long long)total_rerun, rounds);
-        if (total_rerun) {
+        if (query_mode) {
+            // stop every sequence where query_sequence stops it, drop the void records, tag the rest with their read
+            HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (!(u32)h->h_small[1]) {
+                const u64 n3 = std::min<u64>(h->h_small[0], cap);
+                unsigned long long* d_brk = (unsigned long long*)(d_qret + cap);
+                if ((rc = ensure(h, h->parted, (n3 - n1 + 1) * (h->P.stride * 8 + 4)))) return rc;
+                u64* stage = (u64*)h->parted.p;
+                u32* stage_tags = (u32*)(stage + (n3 - n1 + 1) * h->P.stride);
+                HIPCHK(h, hipMemsetAsync(d_brk, 0xff, cap_vr * 8, h->stream));
+                HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
+                if (n3 > n1) {
+                    hipLaunchKernelGGL(k_query_break, dim3(nblocks(n3 - n1, 256)), dim3(256), 0, h->stream, d_qret, d_ctags, n1, n2, n3, d_vr, d_status, d_starts, d_brk);
+                    hipLaunchKernelGGL(k_query_filter, dim3(nblocks(n3 - n1, 256)), dim3(256), 0, h->stream, h->P, d_rec, d_qret, d_ctags, n1, n2, n3, d_vr, d_status,
+                                       d_brk, stage, stage_tags, h->d_small + 6);
+                    if (int lrc = launch_check(h, "k_query_break/filter")) return lrc;
+                }
+                HIPCHK(h, hipMemcpyAsync(h->h_small + 6, h->d_small + 6, 8, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                const u64 kept = h->h_small[6];
+                if (kept) {
+                    HIPCHK(h, hipMemcpyAsync(d_rec + n1 * h->P.stride, stage, kept * h->P.stride * 8, hipMemcpyDeviceToDevice, h->stream));
+                    HIPCHK(h, hipMemcpyAsync(d_ctags + n1, stage_tags, kept * 4, hipMemcpyDeviceToDevice, h->stream));
+                }
+                h->h_small[6] = n1 + kept;  // pinned: stays untouched until the copy below has run
+                HIPCHK(h, hipMemcpyAsync(h->d_small, h->h_small + 6, 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
+            if (hist_valid) *hist_valid = false;
+        } else if (total_rerun) {
             HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (!(u32)h->h_small[1]) {
@@ -645,8 +685,14 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     // d_sums[n_reads] must be zeroed by the caller
     u64 n_rec = 0;
     int rc;
-    if ((rc = scan_to_staging(h, d_packed, d_starts, n_reads, true, true, &n_rec))) return rc;
+    bool hist_ok = true;
+    if ((rc = scan_to_staging(h, d_packed, d_starts, n_reads, true, true, &n_rec, &hist_ok))) return rc;
     if (n_rec == 0) return BRISK_HIP_OK;
+    if (!hist_ok) {  // long sequences were scanned in chunks and cut where the query stops: count the records that are left
+        HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+        hipLaunchKernelGGL(k_part_hist, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, h->P, (const u64*)h->staging.p, n_rec, h->d_hist);
+        if (int lrc = launch_check(h, "k_part_hist")) return lrc;
+    }
     return query_records_impl(h, (const u64*)h->staging.p, (const u32*)h->tags_a.p, n_rec, d_sums);
 }
 
@@ -1387,8 +1433,10 @@ BRISK_API int brisk_hip_scan_query(brisk_hip_index* h, const uint32_t* d_packed,
     HIPCHK(h, hipSetDevice(h->device));
     *n_records = 0;
     if (!n_reads) return BRISK_HIP_OK;
-    u64 n = 0;
-    int rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, true, d_tags, &n);
+    u64 n = 0, bound = 0;
+    int rc = count_kmers(h, d_starts, n_reads, &bound);
+    if (rc) return rc;
+    rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, false, true, d_tags, &n, nullptr, bound);
     *n_records = n;
     return rc;
 }

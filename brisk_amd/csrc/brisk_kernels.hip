@@ -497,6 +497,36 @@ __global__ void __launch_bounds__(256) k_chunk_next(const VRead* __restrict__ vr
     cursor[i] = stop[i] == 0xffffffffu ? 0xffffffffu : stop[i] + 1;
     stop[i] = 0xffffffffu;
 }
+// ---- a query over chunked sequences (query_sequence stops a sequence at the first super-k-mer, other than its
+// first, whose returned minimizer is 0, apps/counter.cpp:304-306).  Chunks cannot know what happened before them,
+// so they emit everything, every record carrying where its vector starts and whether its minimizer is 0
+// (ScanOut::ret); once the chunks are exact, k_query_break finds each sequence's stop and k_query_filter drops what
+// lies at or behind it, along with the speculative records of re-scanned chunks, and tags the rest with their read.
+__global__ void __launch_bounds__(256) k_query_break(const u64* __restrict__ ret, const u32* __restrict__ tags, u64 first, u64 n_spec_end, u64 n_rec,
+                                                     const VRead* __restrict__ vreads, const u32* __restrict__ status, const u64* __restrict__ starts,
+                                                     unsigned long long* __restrict__ brk) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const u32 slot = tags[i];
+    if (i < n_spec_end && (status[slot] & CHUNK_RERUN)) return;
+    const u64 r = ret[i], q = r & 0x7fffffffffffffffull;
+    const VRead v = vreads[slot];
+    if ((r >> 63) && q > starts[v.read]) atomicMin(&brk[v.first], (unsigned long long)q);
+}
+__global__ void __launch_bounds__(256) k_query_filter(BriskParams P, const u64* __restrict__ rec, const u64* __restrict__ ret, const u32* __restrict__ tags, u64 first,
+                                                      u64 n_spec_end, u64 n_rec, const VRead* __restrict__ vreads, const u32* __restrict__ status,
+                                                      const unsigned long long* __restrict__ brk, u64* __restrict__ out, u32* __restrict__ tag_out,
+                                                      unsigned long long* __restrict__ n_out) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const u32 slot = tags[i];
+    if (i < n_spec_end && (status[slot] & CHUNK_RERUN)) return;
+    const VRead v = vreads[slot];
+    if ((ret[i] & 0x7fffffffffffffffull) >= brk[v.first]) return;
+    const unsigned long long o = atomicAdd(n_out, 1ull);
+    for (u32 j = 0; j < P.stride; j++) out[o * P.stride + j] = rec[i * P.stride + j];
+    tag_out[o] = v.read;
+}
 // keep the speculative records of the chunks that were not re-scanned
 __global__ void __launch_bounds__(256) k_filter_records(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags, u64 first, u64 n_rec,
                                                         const u32* __restrict__ status, u64* __restrict__ out, unsigned long long* __restrict__ n_out) {
@@ -542,7 +572,7 @@ __device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32
     for (u32 i = 0; i < wid; i++) base += s_wcnt[i];
     for (u32 e = lane; e < qcount; e += 64) {
         const u32 mi = q_misc[e];
-        emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], 0, base + e);
+        emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], q_start[e] | ((u64)((mi >> 17) & 1) << 63), base + e);
     }
 }
 
@@ -699,7 +729,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             if (push) {
                 const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
                 q_start[at] = q0 + p0;
-                q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16);
+                q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17);
                 q_tag[at] = tagval;
                 n_emitted++;
             }
@@ -791,7 +821,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             base = read_lane_u64(base, 0);
             for (u32 e = lane; e < qcount; e += 64) {
                 const u32 mi = q_misc[e];
-                emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], 0, base + e);
+                emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], q_start[e] | ((u64)((mi >> 17) & 1) << 63), base + e);
             }
             qcount = 0;
         }
@@ -805,7 +835,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         if (push) {
             const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
             q_start[at] = q0 + p0;
-            q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16);
+            q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17);
             q_tag[at] = tagval;
         }
         qcount += (u32)__popcll(bal);

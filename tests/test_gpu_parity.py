@@ -428,6 +428,19 @@ def test_chromosome_length_sequences_are_scanned_in_chunks(B, O):
     seqs.append(rc(seqs[0][1000:150_000]))
     for k, m, b in ((63, 21, 14), (31, 11, 11), (31, 11, 4)):
         assert gpu_count(B, seqs, k, m, b) == O.count(seqs, k, m, b), (k, m, b)
+    # the query path chunks long sequences too and stops each where query_sequence stops it (a returned minimizer of 0:
+    # the poly-A stretches below), whatever chunk that falls in
+    queries = seqs + [rnd(20_000) + "A" * 90 + rnd(20_000), "A" * 70 + rnd(30_000), rnd(9_000) + "A" * 500 + rnd(9_000) + "A" * 64 + rnd(5_000)]
+    for k, m, b in ((63, 21, 14), (31, 11, 11)):
+        flat, offs = oracle.pack_reads(seqs)
+        h = O.index_new(k, m, b)
+        O.index_insert_reads(h, flat, offs)
+        qflat, qoffs = oracle.pack_reads(queries)
+        want = O.index_query_reads(h, qflat, qoffs)
+        O.index_free(h)
+        with B.BriskHip(k, m, b) as ix:
+            ix.insert_reads(seqs)
+            assert np.array_equal(ix.get_reads(queries), want), (k, m, b)
     # and as two batches, through the records API used for sharding (scan -> insert_records)
     import torch
     k, m, b = 63, 21, 14

@@ -61,6 +61,19 @@ def main():
         n = ix.stats()["nb_kmers"]
         print("one %d Mbp sequence (chunked scan): %d entries in %.1f ms = %.2f G k-mers/s; kernels %s"
               % (G // 1_000_000, n, dt * 1e3, (G - k + 1) / dt / 1e9, {a: round(v["ms"], 2) for a, v in prof.items() if v["launches"]}))
+        # the same sequence queried back: query-mode scan (chunked too), then one sum per record
+        cap = ix.scan_bound(d_starts.data_ptr(), 1) // 8 + 4096
+        d_rec = torch.empty(cap * ix.record_words, dtype=torch.int64, device="cuda")
+        d_tags = torch.empty(cap, dtype=torch.int32, device="cuda")
+        d_sums = torch.empty(cap, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):
+            t0 = time.perf_counter()
+            n_rec = ix.scan_query(d_packed.data_ptr(), d_starts.data_ptr(), 1, d_rec.data_ptr(), d_tags.data_ptr(), cap)
+            ix.query_records(d_rec.data_ptr(), n_rec, d_sums.data_ptr())
+            total = int(d_sums[:n_rec].sum().item())
+            dt = time.perf_counter() - t0
+        print("queried back: %d records, sum of counts %d (k-mers %d) in %.1f ms" % (n_rec, total, G - k + 1, dt * 1e3))
 
 
 if __name__ == "__main__":
