@@ -1350,16 +1350,22 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
     }
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
-                                               u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
-    __shared__ u64 s_key[2 * WI_MAX_INST];
-    __shared__ u64 s_rec[WI_MAX_REC * 5 > WI_MAX_INST / 2 ? WI_MAX_REC * 5 : WI_MAX_INST / 2];
-    __shared__ u32 s_tab[WI_TABLE];
+// MAXI: k-mer instances per chunk.  256 (10 KB of LDS, 128 registers: 4 waves per SIMD) for the usual partitions of a
+// few hundred instances; 512 (2 waves per SIMD) when partitions are big -- few distinct minimizers, as with m <= 11 --
+// and the passes over a partition's entries saved by half as many chunks outweigh the occupancy.
+template <u32 MAXI>
+__device__ __forceinline__ void insert_body(const BriskParams& P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
+                                            u32* __restrict__ work_counter) {
+    constexpr u32 TABLE = 2 * MAXI, TS = TABLE / 64, NI = MAXI / 64;
+    static_assert(MAXI % 256 == 0 && MAXI <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
+    __shared__ u64 s_key[2 * MAXI];
+    __shared__ u64 s_rec[WI_MAX_REC * 5 > MAXI / 2 ? WI_MAX_REC * 5 : MAXI / 2];
+    __shared__ u32 s_tab[TABLE];
     __shared__ u32 s_pref[WI_MAX_REC + 1];
-    u32* s_list = (u32*)s_rec;  // [WI_MAX_INST] the new entries' table words: built after the records have been expanded
+    u32* s_list = (u32*)s_rec;  // [MAXI] the new entries' table words: built after the records have been expanded
     __shared__ u32 s_rtab[2 * WI_MAX_REC];
     __shared__ u32 s_rmult[WI_MAX_REC];
-    __shared__ __attribute__((aligned(4))) uint8_t s_irec[WI_MAX_INST];
+    __shared__ __attribute__((aligned(4))) uint8_t s_irec[MAXI];
     __shared__ u32 s_bm[2];
 
     const u32 lane = threadIdx.x;
@@ -1392,7 +1398,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
             u32 bm0 = 0, bm1 = 0;
 
             for (u32 rc = d.r_begin; rc < r_end;) {
-                // ---- pick the chunk: up to WI_MAX_REC records / WI_MAX_INST instances
+                // ---- pick the chunk: up to WI_MAX_REC records / MAXI instances
                 const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
                 if (rc != d.r_begin) rr = load_rec_regs(P, rec, rc, avail, lane);
                 wave_sync();
@@ -1412,7 +1418,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 // If the collapsed chunk is still too big, shrink to the prefix whose collapsed count fits (counted
                 // again on its own it can come out a little higher, once the first copy of a record lies beyond
                 // it: hence the loop), at the latest to the raw-count prefix, which always fits.
-                const u32 rawfit = (u32)__popcll(__ballot(lane < avail && x0 <= WI_MAX_INST));  // >= 1; a prefix: x0 is monotone
+                const u32 rawfit = (u32)__popcll(__ballot(lane < avail && x0 <= MAXI));  // >= 1; a prefix: x0 is monotone
                 u32 nrec = avail, my_n = 0, x = 0, ninst = 0;
                 for (int attempt = 0;; attempt++) {
                     s_rtab[lane] = EMPTY_SLOT;
@@ -1443,42 +1449,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                     my_n = (lane < nrec && !dup) ? raw_n : 0;
                     x = wave_incl_scan(my_n, lane);
                     ninst = __shfl(x, 63, 64);
-                    if (ninst <= WI_MAX_INST) break;
-                    const u32 fit = (u32)__popcll(__ballot(lane < nrec && x <= WI_MAX_INST));  // x is monotone too
+                    if (ninst <= MAXI) break;
+                    const u32 fit = (u32)__popcll(__ballot(lane < nrec && x <= MAXI));  // x is monotone too
                     nrec = (attempt >= 2 || fit <= rawfit) ? rawfit : min(fit, nrec - 1);
                     wave_sync();
                 }
                 const u32 raw_inst = __shfl(x0, nrec - 1, 64);
                 u32 tsize = 128;
-                while (tsize < 2 * ninst && tsize < WI_TABLE) tsize <<= 1;
+                while (tsize < 2 * ninst && tsize < TABLE) tsize <<= 1;
                 s_pref[lane + 1] = x;
                 if (lane == 0) s_pref[0] = 0;
 #pragma unroll
-                for (u32 w = 0; w < WI_TS; w++)
+                for (u32 w = 0; w < TS; w++)
                     if (w * 64 < tsize) s_tab[w * 64 + lane] = EMPTY_SLOT;
                 {
                     // instance -> record: each record marks its first instance, a running maximum spreads the marks
-                    // (records lie in lane order).  Every lane owns WI_MAX_INST/64 consecutive instances here.
+                    // (records lie in lane order).  Every lane owns MAXI/64 consecutive instances here.
                     u32* irec32 = (u32*)s_irec;
 #pragma unroll
-                    for (u32 q = 0; q < WI_MAX_INST / 256; q++) irec32[q * 64 + lane] = 0;
+                    for (u32 q = 0; q < MAXI / 256; q++) irec32[q * 64 + lane] = 0;
                     wave_sync();
                     if (my_n) s_irec[x - my_n] = (uint8_t)(lane + 1);
                     wave_sync();
-                    u32 wv[WI_MAX_INST / 256], run = 0;
+                    u32 wv[MAXI / 256], run = 0;
 #pragma unroll
-                    for (u32 q = 0; q < WI_MAX_INST / 256; q++) {
-                        wv[q] = irec32[lane * (WI_MAX_INST / 256) + q];
+                    for (u32 q = 0; q < MAXI / 256; q++) {
+                        wv[q] = irec32[lane * (MAXI / 256) + q];
                         run = op_max_u32(run, op_max_u32(op_max_u32(wv[q] & 0xff, (wv[q] >> 8) & 0xff), op_max_u32((wv[q] >> 16) & 0xff, wv[q] >> 24)));
                     }
                     u32 carry = wave_prev_lane(wave_incl_max_scan(run));  // the last mark before this lane's instances
 #pragma unroll
-                    for (u32 q = 0; q < WI_MAX_INST / 256; q++) {
+                    for (u32 q = 0; q < MAXI / 256; q++) {
                         const u32 b0 = op_max_u32(carry, wv[q] & 0xff), b1 = op_max_u32(b0, (wv[q] >> 8) & 0xff);
                         const u32 b2 = op_max_u32(b1, (wv[q] >> 16) & 0xff), b3 = op_max_u32(b2, wv[q] >> 24);
                         carry = b3;
                         // marks are lane + 1; instances past the last record (none are read) may hold 0 - 1
-                        irec32[lane * (WI_MAX_INST / 256) + q] = ((b0 - 1) & 0xff) | (((b1 - 1) & 0xff) << 8) | (((b2 - 1) & 0xff) << 16) | ((b3 - 1) << 24);
+                        irec32[lane * (MAXI / 256) + q] = ((b0 - 1) & 0xff) | (((b1 - 1) & 0xff) << 8) | (((b2 - 1) & 0xff) << 16) | ((b3 - 1) << 24);
                     }
                 }
                 wave_sync();
@@ -1490,10 +1496,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                     if (ninst <= 64) expand_and_dedupe<1, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else if (ninst <= 128) expand_and_dedupe<2, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else if (ninst <= 192) expand_and_dedupe<3, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else expand_and_dedupe<WI_NI, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else expand_and_dedupe<NI, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                 } else {
                     if (ninst <= 128) expand_and_dedupe<2, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else expand_and_dedupe<WI_NI, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else expand_and_dedupe<NI, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                 }
                 wave_sync();
 
@@ -1540,7 +1548,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                 // full waves (a store instruction costs the same with 3 active lanes as with 64)
                 u32 n_new = 0;
 #pragma unroll
-                for (u32 w = 0; w < WI_TS; w++) {
+                for (u32 w = 0; w < TS; w++) {
                     if (w * 64 < tsize) {
                         const u32 v = s_tab[w * 64 + lane];
                         const bool is_new = v != EMPTY_SLOT && !(v & MATCHED_BIT);
@@ -1572,8 +1580,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
                         noff = acur;
                         acur += want;
                     }
-                    if (noff + want > ix.arena_cap || ninst > WI_MAX_INST) {  // must not happen (host reserves the bound): drop, flag
-                        if (lane == 0) atomicOr(ix.err, ninst > WI_MAX_INST ? 4u : 2u);
+                    if (noff + want > ix.arena_cap || ninst > MAXI) {  // must not happen (host reserves the bound): drop, flag
+                        if (lane == 0) atomicOr(ix.err, ninst > MAXI ? 4u : 2u);
                         break;
                     }
                     garbage += cap;
@@ -1638,6 +1646,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVE
         ix.slot_end[blockIdx.x] = aend;
         if (garbage) atomicAdd(&ix.stats[3], garbage);
     }
+}
+
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+                                               u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
+    insert_body<WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+                                                                                         u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
+    insert_body<2 * WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
 }
 
 // bucket occupancy for partitions wider than 64 buckets (small part_bits): one pass over all entries
