@@ -280,9 +280,14 @@ __device__ __forceinline__ u128x entry_hashed_kmer(const BriskParams& P, u32 par
     *idx_out = idxp - P.suff_reduc;
     return r;
 }
+// slot hash of an entry key for the LDS tables: rotate-xor fold of the four 32-bit words, one 32-bit multiply
+// (64-bit multiplies are four quarter-rate instructions each, and this runs once per k-mer instance and per
+// streamed entry)
 __device__ __forceinline__ u32 hash_key32(u128x k) {
-    u64 z = k.lo ^ (k.hi * 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
-    z ^= z >> 29;
-    return (u32)z;
+    const u32 a = (u32)k.lo, b = (u32)(k.lo >> 32), c = (u32)k.hi, d = (u32)(k.hi >> 32);
+    u32 z = a ^ ((b << 7) | (b >> 25)) ^ ((c << 13) | (c >> 19)) ^ ((d << 21) | (d >> 11));
+    z ^= z >> 16;
+    z *= 0x85EBCA6Bu;
+    z ^= z >> 13;
+    return z;
 }
