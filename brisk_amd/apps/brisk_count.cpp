@@ -64,11 +64,19 @@ int main(int argc, char** argv) {
                 }
             }
             kmer_full km((kint)0, 0, m, params.dede);
+            bool first_entry = true;
             while (index.next(km)) {
                 uint8_t* c = index.get(km);
                 if (!c) {
                     std::cerr << "entry without data" << std::endl;
                     return 1;
+                }
+                if (first_entry) {  // Brisk::insert on a k-mer that is present behaves like get (README.md:49 of the reference)
+                    first_entry = false;
+                    if (index.insert(km) != c) {
+                        std::cerr << "insert(kmer) of a present k-mer is not its get" << std::endl;
+                        return 1;
+                    }
                 }
                 sum += *c;
                 if (dump) lines.push_back(kmer2str(km.kmer_s, k) + " " + std::to_string(km.minimizer_idx) + " " + std::to_string(*c));

@@ -36,6 +36,14 @@ class Brisk {
         std::vector<kmer_full> one(1, kmer);
         return find(one)[0];
     }
+    // README.md:49-50,63,136 of the reference document `insert(kmer)` ("if absent, allocate a DATA space and return a
+    // pointer to it; if present, similar to get") although brisk/Brisk.hpp never defines it: a thin extra over
+    // insert_superkmer.  The DATA of a new entry is uninitialised, as with insert_superkmer.
+    DATA* insert(kmer_full& kmer) {
+        std::vector<kmer_full> one(1, kmer);
+        std::vector<bool> fresh;
+        return insert_superkmer(one, fresh)[0];
+    }
     // brisk/Brisk.hpp:123-147: entries that were absent are created; their DATA is uninitialised and
     // newly_inserted[i] tells the caller to initialise it.  Pointers stay valid for the life of the index.
     std::vector<DATA*> insert_superkmer(std::vector<kmer_full>& superkmer, std::vector<bool>& newly_inserted) {
