@@ -109,14 +109,17 @@ class ShardedCounter:
         self._cap = 0
 
     def count_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> None:
-        """Count this rank's reads into the sharded index.  The reads go in two halves so that the all-to-all of the
-        first half's records runs while the second half is scanned; the owner inserts everything it received at once."""
+        """Count this rank's reads into the sharded index.  The reads go in pieces (four for a large batch) so that the
+        all-to-all of one piece's records runs while the next piece is scanned; the owner inserts everything it received
+        at once."""
         ix, W = self.ix, self.W
         if self.world == 1:
             ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
             return
         import brisk_amd
-        halves = [(0, n_reads // 2), (n_reads // 2, n_reads)] if n_reads >= 2 else [(0, n_reads)]
+        pieces = 4 if n_reads >= (1 << 22) else (2 if n_reads >= 2 else 1)  # only the last piece's all-to-all is exposed
+        cuts = [n_reads * i // pieces for i in range(pieces + 1)]
+        halves = list(zip(cuts[:-1], cuts[1:]))
         n_parts = 1 << ix.layout["part_bits"]
         with torch.cuda.stream(self.stream):
             cap = self._cap or (n_reads * 6 + 4096)
