@@ -105,3 +105,24 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["verify"]["every_kmer_counted_once"] is True
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_matches_single_rank():
+    """The N>1 flow of bench.py (pieces, route, all-to-alls of records and histogram slices, one insert per owner) on
+    two gloo ranks sharing the GPU builds the same index -- entry count and digest -- as one rank over the same reads."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "600000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--reads", "300000",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    v1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["verify"]
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    v2 = d2["verify"]
+    assert d2["n_gpus"] == 2 and v2["every_kmer_counted_once"]
+    for key in ("entries", "nb_kmers", "nb_buckets", "sum_counts", "digest_mod_2_64"):
+        assert v1[key] == v2[key], key
