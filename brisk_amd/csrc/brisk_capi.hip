@@ -427,7 +427,7 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         else
             hipLaunchKernelGGL(k_insert, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (const u64*)h->parted.p,
                                (const PartDesc*)h->desc.p, n_touched, h->ix, (u32*)(h->d_small + 6));
-        if ((rc = launch_check(h, "k_insert"))) return rc;
+        if ((rc = launch_check(h, n_rec / n_touched > 64 ? "k_insert_big" : "k_insert"))) return rc;
     }
     h->nb_skmers += n_rec;
     h->dir_snapshot_valid = false;
