@@ -1212,12 +1212,6 @@ static_assert(WI_MAX_INST % 256 == 0 && WI_MAX_INST <= 1024, "chunk size: whole 
 #define WI_IDX_MASK 0x3ffu
 #define wave_sync() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
-__device__ __forceinline__ u32 table_size_for(u32 ninst) {
-    u32 t = 128;
-    while (t < 2 * ninst && t < WI_TABLE) t <<= 1;
-    return t;
-}
-
 // record words of the calling lane's record (lane r < n loads record first+r), 5 words at most
 struct RecRegs {
     u64 w0, w1, w2, w3, w4;
@@ -1264,7 +1258,6 @@ __device__ __forceinline__ u32 wave_incl_max_scan(u32 x) {
 // value of the previous lane (0 for lane 0)
 __device__ __forceinline__ u32 wave_prev_lane(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }  // wave_shr:1
 
-#define WI_NI (WI_MAX_INST / 64)   // instances per lane
 #define WI_TS (WI_TABLE / 64)      // table words per lane
 
 // k-mer j of record words in LDS, branch-free (every load is unconditional so that the
@@ -1284,7 +1277,7 @@ __device__ __forceinline__ u128x record_kmer_lds(const BriskParams& P, const u64
 
 #define WI_BATCH 64u   // partitions a wave takes per work-counter atomic (same-address atomics serialise device-wide)
 
-// WI_NI-instances-per-lane body of the expand + de-duplicate phases (NI = 4 when the
+// NI-instances-per-lane body of the expand + de-duplicate phases (NI = 4 when the
 // chunk has <= 256 instances, else 8: all NI instances of a lane are in flight together)
 template <u32 NI, u32 NW>
 __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane, u32 ninst, u32 tsize, const u64* s_rec, const u32* s_pref,
