@@ -422,10 +422,10 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         // with them half as many passes over a partition's entries, outweigh its 2 waves per SIMD (k31/m11/b11: 48 -> 36 ms)
         const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
         if (n_rec / n_touched > 64)
-            hipLaunchKernelGGL(k_insert_big, dim3(std::min<u32>(batches, INSERT_SLOTS / 2)), dim3(64), 0, h->stream, P, (const u64*)h->parted.p,
+            hipLaunchKernelGGL(k_insert_big, dim3(std::min<u32>(batches, INSERT_SLOTS / 2)), dim3(64), 0, h->stream, P, (u64*)h->parted.p,
                                (const PartDesc*)h->desc.p, n_touched, h->ix, (u32*)(h->d_small + 6));
         else
-            hipLaunchKernelGGL(k_insert, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (const u64*)h->parted.p,
+            hipLaunchKernelGGL(k_insert, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (u64*)h->parted.p,
                                (const PartDesc*)h->desc.p, n_touched, h->ix, (u32*)(h->d_small + 6));
         if ((rc = launch_check(h, n_rec / n_touched > 64 ? "k_insert_big" : "k_insert"))) return rc;
     }

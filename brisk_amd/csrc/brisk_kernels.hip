@@ -1301,7 +1301,7 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
         klo[it] = key.lo;
         khi[it] = key.hi;
         hh[it] = hash_key32(key) & (tsize - 1);
-        mult[it] = s_rmult[r] << WI_CNT_SHIFT;
+        mult[it] = (s_rmult[r] & 0xffu) << WI_CNT_SHIFT;  // counts wrap at 256: so may the multiplicities
         if (i < ninst) {
             s_key[2 * i] = key.lo;
             s_key[2 * i + 1] = key.hi;
@@ -1343,11 +1343,48 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
     }
 }
 
+// Record-level de-duplication of the <= 64 records the lanes hold (also in s_rec): the first copy of every distinct record
+// survives, s_rmult[its lane] = the multiplicities of all its copies added up; returns whether this lane's record is a
+// later copy.  Header bits 48..55 carry a record's multiplicity (mod 256: counts wrap there anyway) once a partition's
+// records have been collapsed; they are not part of its identity.
+#define HDR_ID_MASK 0x0000ffffffffffffull
+__device__ __forceinline__ bool dedupe_records(u32 stride, const RecRegs& rr, u32 my_mult, u32 nrec, u32 lane, const u64* s_rec, u32* s_rtab, u32* s_rmult) {
+    s_rtab[lane] = EMPTY_SLOT;
+    s_rtab[lane + 64] = EMPTY_SLOT;
+    s_rmult[lane] = my_mult;
+    wave_sync();
+    bool dup = false;
+    if (lane < nrec) {
+        const u64 k1 = stride == 2 ? HDR_ID_MASK : ~0ull, k2 = stride == 3 ? HDR_ID_MASK : ~0ull, k3 = stride == 4 ? HDR_ID_MASK : ~0ull,
+                  k4 = stride == 5 ? HDR_ID_MASK : ~0ull;
+        const u64 w1 = rr.w1 & k1, w2 = rr.w2 & k2, w3 = rr.w3 & k3, w4 = rr.w4 & k4;
+        // a weak hash is enough for <= 64 records in 128 slots: rotate-xor fold, one 32-bit multiply
+        const u64 z = rr.w0 ^ ((w1 << 17) | (w1 >> 47)) ^ ((w2 << 31) | (w2 >> 33)) ^ ((w3 << 47) | (w3 >> 17)) ^ w4;
+        u32 h = ((((u32)z ^ (u32)(z >> 32)) * 0x9E3779B1u) >> 20) & (2 * WI_MAX_REC - 1);
+        for (;;) {
+            const u32 o = atomicCAS(&s_rtab[h], EMPTY_SLOT, lane);
+            if (o == EMPTY_SLOT) break;
+            const u64* oc = s_rec + o * stride;
+            bool same = oc[0] == rr.w0 && (oc[1] & k1) == w1;
+            if (stride > 2) same = same && (oc[2] & k2) == w2;
+            if (stride > 3) same = same && (oc[3] & k3) == w3;
+            if (stride > 4) same = same && (oc[4] & k4) == w4;
+            if (same) {
+                atomicAdd(&s_rmult[o], my_mult);
+                dup = true;
+                break;
+            }
+            h = (h + 1) & (2 * WI_MAX_REC - 1);
+        }
+    }
+    return dup;
+}
+
 // MAXI: k-mer instances per chunk.  256 (10 KB of LDS, 128 registers: 4 waves per SIMD) for the usual partitions of a
 // few hundred instances; 512 (2 waves per SIMD) when partitions are big -- few distinct minimizers, as with m <= 11 --
 // and the passes over a partition's entries saved by half as many chunks outweigh the occupancy.
 template <u32 MAXI>
-__device__ __forceinline__ void insert_body(const BriskParams& P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
+__device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
                                             u32* __restrict__ work_counter) {
     constexpr u32 TABLE = 2 * MAXI, TS = TABLE / 64, NI = MAXI / 64;
     static_assert(MAXI % 256 == 0 && MAXI <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
@@ -1383,12 +1420,52 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, const u64* __r
             RecRegs rn{0, 0, 0, 0, 0};
 
             const u32 part = d.part;
-            const u32 r_end = d.r_begin + d.n_rec;
+            u32 r_end = d.r_begin + d.n_rec;
             u32 n_exist = d.n_exist;
             u32 inst_left = d.n_inst;  // instances not yet processed: bounds the final size
             unsigned long long off = d.off;
             u32 cap = d.cap;
             u32 bm0 = 0, bm1 = 0;
+
+            // A partition of many records (one hot bucket) first collapses its records window by window, in place:
+            // the chunks below then see each distinct record of a window once, with its multiplicity in the header,
+            // and far fewer chunks -- each of which streams the partition's entries -- are needed.
+            // (only in the big-partition kernel: the usual one is 2-3 % slower with this path compiled in)
+            bool collapsed = false;
+            if (MAXI > WI_MAX_INST && d.n_rec > 2 * WI_MAX_REC) {
+                u32 wr = d.r_begin;
+                for (u32 rd = d.r_begin; rd < r_end; rd += WI_MAX_REC) {
+                    const u32 avail = min(r_end - rd, (u32)WI_MAX_REC);
+                    if (rd != d.r_begin) rr = load_rec_regs(P, rec, rd, avail, lane);
+                    wave_sync();
+                    if (lane < avail) {
+                        u64* dst = s_rec + lane * P.stride;
+                        dst[0] = rr.w0;
+                        dst[1] = rr.w1;
+                        if (P.stride > 2) dst[2] = rr.w2;
+                        if (P.stride > 3) dst[3] = rr.w3;
+                        if (P.stride > 4) dst[4] = rr.w4;
+                    }
+                    const bool dup = dedupe_records(P.stride, rr, 1u, avail, lane, s_rec, s_rtab, s_rmult);
+                    wave_sync();
+                    const bool keep = lane < avail && !dup;
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {  // survivors move to the front of the partition's records (never past what is still to be read)
+                        u64* dst = rec + (u64)(wr + (u32)__popcll(bal & lanes_below(lane))) * P.stride;
+                        const u64 mult = (u64)(s_rmult[lane] & 0xffu) << 48;
+                        dst[0] = rr.w0;
+                        dst[1] = P.stride == 2 ? rr.w1 | mult : rr.w1;
+                        if (P.stride > 2) dst[2] = P.stride == 3 ? rr.w2 | mult : rr.w2;
+                        if (P.stride > 3) dst[3] = P.stride == 4 ? rr.w3 | mult : rr.w3;
+                        if (P.stride > 4) dst[4] = rr.w4 | mult;
+                    }
+                    wr += (u32)__popcll(bal);
+                }
+                collapsed = true;
+                r_end = wr;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the chunks read what was just written: same wave, same CU
+                rr = load_rec_regs(P, rec, d.r_begin, min(r_end - d.r_begin, (u32)WI_MAX_REC), lane);
+            }
 
             for (u32 rc = d.r_begin; rc < r_end;) {
                 // ---- pick the chunk: up to WI_MAX_REC records / MAXI instances
@@ -1405,6 +1482,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, const u64* __r
                 }
                 const u64 my_hdr = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
                 const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
+                const u32 my_mult = collapsed ? (u32)(my_hdr >> 48) & 0xffu : 1u;
                 const u32 x0 = wave_incl_scan(raw_n, lane);
                 // First try every available record: identical records (the same super-k-mer seen in
                 // several reads) collapse into one with a multiplicity, so far more raw instances fit.
@@ -1414,31 +1492,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, const u64* __r
                 const u32 rawfit = (u32)__popcll(__ballot(lane < avail && x0 <= MAXI));  // >= 1; a prefix: x0 is monotone
                 u32 nrec = avail, my_n = 0, x = 0, ninst = 0;
                 for (int attempt = 0;; attempt++) {
-                    s_rtab[lane] = EMPTY_SLOT;
-                    s_rtab[lane + 64] = EMPTY_SLOT;
-                    s_rmult[lane] = 1;
-                    wave_sync();
-                    bool dup = false;
-                    if (lane < nrec) {
-                        // a weak hash is enough for <= 64 records in 128 slots: rotate-xor fold, one 32-bit multiply
-                        const u64 z = rr.w0 ^ ((rr.w1 << 17) | (rr.w1 >> 47)) ^ ((rr.w2 << 31) | (rr.w2 >> 33)) ^ ((rr.w3 << 47) | (rr.w3 >> 17)) ^ rr.w4;
-                        u32 h = ((((u32)z ^ (u32)(z >> 32)) * 0x9E3779B1u) >> 20) & (2 * WI_MAX_REC - 1);
-                        for (;;) {
-                            const u32 o = atomicCAS(&s_rtab[h], EMPTY_SLOT, lane);
-                            if (o == EMPTY_SLOT) break;
-                            const u64* oc = s_rec + o * P.stride;
-                            bool same = oc[0] == rr.w0 && oc[1] == rr.w1;
-                            if (P.stride > 2) same = same && oc[2] == rr.w2;
-                            if (P.stride > 3) same = same && oc[3] == rr.w3;
-                            if (P.stride > 4) same = same && oc[4] == rr.w4;
-                            if (same) {
-                                atomicAdd(&s_rmult[o], 1u);
-                                dup = true;
-                                break;
-                            }
-                            h = (h + 1) & (2 * WI_MAX_REC - 1);
-                        }
-                    }
+                    const bool dup = dedupe_records(P.stride, rr, my_mult, nrec, lane, s_rec, s_rtab, s_rmult);
                     my_n = (lane < nrec && !dup) ? raw_n : 0;
                     x = wave_incl_scan(my_n, lane);
                     ninst = __shfl(x, 63, 64);
@@ -1642,11 +1696,11 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, const u64* __r
 }
 
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
                                                u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
     insert_body<WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
 }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, const u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
                                                                                          u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
     insert_body<2 * WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
 }
