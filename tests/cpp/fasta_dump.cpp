@@ -5,7 +5,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
-    FastaBatcher batches(argv[1], (size_t)atoll(argv[2]));
+    FastaBatcher batches(argv[1], (size_t)atoll(argv[2]), argc > 3 ? (unsigned)atoi(argv[3]) : 0u);  // threads for a plain file (0: default)
     FastaBatch b;
     while (batches.next(b))
         for (size_t i = 0; i < b.size(); i++) std::cout << b.flat.substr(b.offs[i], b.offs[i + 1] - b.offs[i]) << "\n";

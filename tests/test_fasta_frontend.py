@@ -21,8 +21,8 @@ def dumper(tmp_path_factory):
     return exe
 
 
-def run(dumper, path, batch):
-    out = subprocess.run([dumper, path, str(batch)], capture_output=True, text=True, timeout=120)
+def run(dumper, path, batch, threads=0):
+    out = subprocess.run([dumper, path, str(batch), str(threads)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     return [l for l in out.stdout.split("\n") if l]
 
@@ -61,3 +61,24 @@ def test_ragged_input(dumper, tmp_path):
     p3 = str(tmp_path / "nohdr.fa")
     open(p3, "w").write("ACGTACGT\nGGGG\n>z\nCCCC\n")
     assert run(dumper, p3, 100) == ["GGGG", "CCCC"]
+
+
+def test_plain_files_are_parsed_by_several_threads(dumper, tmp_path):
+    """A plain file is mapped and each batch is cut into runs of whole records, one per thread: the sequences and
+    their order do not depend on the number of threads or on the batch size (records of very different lengths,
+    some longer than a batch, headers with '>' inside, empty records)."""
+    rng = random.Random(12)
+    recs = []
+    for i in range(400):
+        n = rng.choice([0, 5, 80, 300, 3000, 20000]) if rng.random() < 0.3 else rng.randint(1, 500)
+        body = "".join(rng.choice("ACGTNacgt") if rng.random() < 0.02 else rng.choice("ACGT") for _ in range(n))
+        lines = [body[j:j + 70] for j in range(0, len(body), 70)]
+        recs.append(">r%d a>b|c\n" % i + "\n".join(lines))
+    text = "\n".join(recs) + "\n"
+    p = str(tmp_path / "many.fa")
+    open(p, "w").write(text)
+    want = oracle.fasta_sequences(text)
+    assert want
+    for batch in (200, 7000, 1 << 20):
+        for threads in (1, 2, 5, 8):
+            assert run(dumper, p, batch, threads) == want, (batch, threads)
