@@ -122,11 +122,12 @@ class ShardedCounter:
         halves = list(zip(cuts[:-1], cuts[1:]))
         n_parts = 1 << ix.layout["part_bits"]
         with torch.cuda.stream(self.stream):
-            cap = self._cap or (n_reads * 6 + 4096)
-            if self._rec is None or self._rec.numel() < cap * W:
+            # record capacity of one piece (scan output, routed copy); the inbox takes what all pieces bring, with room for skew
+            cap = self._cap or (max(hi - lo for lo, hi in halves) * 6 + 4096)
+            if self._rec is None or self._rec.numel() < cap * W or len(self._out) != len(halves):
                 self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
                 self._out = [torch.empty(cap * W, dtype=torch.int64, device=self.dev) for _ in halves]
-                self._inbox = torch.empty((cap + cap // 4) * W, dtype=torch.int64, device=self.dev)
+                self._inbox = torch.empty(len(halves) * (cap + cap // 4) * W, dtype=torch.int64, device=self.dev)
             if self._hist is None:
                 self._hist = [torch.empty(n_parts, dtype=torch.int64, device=self.dev) for _ in halves]
             slices = None
