@@ -1,0 +1,599 @@
+// brisk_insert.hip -- the index: partition directory, arena, k_insert (one wave per partition), bucket bits, stats.
+// Included by brisk_kernels.hip (one translation unit).
+// ===========================================================================
+// k_insert: persistent workgroups, each walking a strided share of the touched
+// partitions.  Per partition (per chunk of at most WI_MAX_INST k-mer instances):
+//   0. every k-mer instance of the chunk's records is expanded to its 128-bit
+//      entry key in LDS (one wave per record, one lane per k-mer);
+//   1. the instances are de-duplicated in an LDS table whose slots hold the index
+//      of the first instance and a multiplicity;
+//   2. the partition's existing entries stream through the table: a hit adds the
+//      multiplicity to the entry's count (uint8_t, wraps; counter.cpp:264-268);
+//   3. unmatched table entries are appended as new entries (count = multiplicity).
+// Storage per partition: keys[] (u128) and counts[] (u8) in a bump-allocated arena.
+// A partition that outgrows its slice moves to a fresh one taken from the
+// workgroup's private arena chunk, so the global cursor sees one atomic per
+// ARENA_CHUNK entries.  nb_kmers / nb_buckets are reductions done at stats() time:
+// the kernel has no same-address global atomics on its data path.
+#ifndef ARENA_CHUNK
+#define ARENA_CHUNK 16384u   // entries a persistent wave takes from the global cursor at a time
+#endif
+// k_insert is bound by each wave's own serial instruction stream (LDS round trips, short dependent
+// chains), so throughput follows the number of resident waves: chunks of 256 instances keep LDS at
+// 10 KB and registers at 128 per wave => 4 waves per SIMD (512-instance chunks: 16 KB, 201 registers,
+// 2 waves per SIMD, 61 ms instead of 50 ms on the 50M-read job; 128-instance chunks spill and split
+// too many partitions: 84 ms).
+#ifndef INSERT_SLOTS
+#define INSERT_SLOTS 4096u   // persistent waves == private allocator slots (256 CUs x 4 SIMDs x 4 waves)
+#endif
+#ifndef WI_WAVES_PER_EU
+#define WI_WAVES_PER_EU 4
+#endif
+struct IndexDev {
+    u64* keys;                   // 2 u64 per entry
+    uint8_t* counts;
+    DirEnt* dir;
+    unsigned long long* cursor;  // arena entries handed out
+    u32* bucket_bits;            // one bit per bucket id
+    unsigned long long* stats;   // [3] garbage entries (abandoned slices)
+    unsigned long long* slot_cur;  // per persistent workgroup: private chunk [cur, end)
+    unsigned long long* slot_end;
+    u32* ids;                    // entry-id mode only: stable dense id of every entry (insertion order)
+    unsigned long long arena_cap;  // entries the arena can hold
+    u32* err;                    // sticky violation bits: 1 scatter slot out of range, 2 arena exhausted, 4 chunk overflow
+};
+
+// k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
+// independent stream of partitions, so a CU keeps ~10 of them in flight and their
+// LDS / HBM latencies overlap.  Sized for partitions of a few hundred k-mer
+// instances (part_bits = 24 at b = 14: 16 buckets per partition).
+#ifndef WI_MAX_INST
+#define WI_MAX_INST 256     // k-mer instances per chunk
+#endif
+#define WI_TABLE (2 * WI_MAX_INST)   // LDS table slots (load <= 0.5)
+static_assert(WI_MAX_INST % 256 == 0 && WI_MAX_INST <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
+#define WI_MAX_REC 64       // records per chunk: one per lane
+#define WI_CNT_SHIFT 10     // table word = [MATCHED | multiplicity (21 b) | instance (10 b)]
+#define WI_IDX_MASK 0x3ffu
+#define wave_sync() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+// record words of the calling lane's record (lane r < n loads record first+r), 5 words at most
+struct RecRegs {
+    u64 w0, w1, w2, w3, w4;
+};
+__device__ __forceinline__ RecRegs load_rec_regs(const BriskParams& P, const u64* __restrict__ rec, u32 first, u32 n, u32 lane) {
+    RecRegs r{0, 0, 0, 0, 0};
+    if (lane < n) {
+        const u64* c = rec + (u64)(first + lane) * P.stride;
+        r.w0 = c[0];
+        r.w1 = c[1];
+        if (P.stride > 2) r.w2 = c[2];
+        if (P.stride > 3) r.w3 = c[3];
+        if (P.stride > 4) r.w4 = c[4];
+    }
+    return r;
+}
+// Inclusive scans over the 64 lanes on the DPP network: row_shr 1,2,4,8 inside each row of 16, then row_bcast15
+// and row_bcast31 carry the row totals over.  Lanes without a source keep the identity 0.  Full EXEC mask only.
+#define WAVE_SCAN_STEP(x, OP, CTRL, ROW_MASK)                                                         \
+    {                                                                                                 \
+        const u32 y_ = (u32)__builtin_amdgcn_update_dpp(0, (int)(x), CTRL, ROW_MASK, 0xf, false); \
+        x = OP(x, y_);                                                                                \
+    }
+__device__ __forceinline__ u32 op_add_u32(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 op_max_u32(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 wave_incl_scan(u32 x, u32 /*lane*/) {
+    WAVE_SCAN_STEP(x, op_add_u32, 0x111, 0xf)  // row_shr:1
+    WAVE_SCAN_STEP(x, op_add_u32, 0x112, 0xf)  // row_shr:2
+    WAVE_SCAN_STEP(x, op_add_u32, 0x114, 0xf)  // row_shr:4
+    WAVE_SCAN_STEP(x, op_add_u32, 0x118, 0xf)  // row_shr:8
+    WAVE_SCAN_STEP(x, op_add_u32, 0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    WAVE_SCAN_STEP(x, op_add_u32, 0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ u32 wave_incl_max_scan(u32 x) {
+    WAVE_SCAN_STEP(x, op_max_u32, 0x111, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x112, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x114, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x118, 0xf)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x142, 0xa)
+    WAVE_SCAN_STEP(x, op_max_u32, 0x143, 0xc)
+    return x;
+}
+// value of the previous lane (0 for lane 0)
+__device__ __forceinline__ u32 wave_prev_lane(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }  // wave_shr:1
+
+#define WI_TS (WI_TABLE / 64)      // table words per lane
+
+// k-mer j of record words in LDS, branch-free (every load is unconditional so that the
+// unrolled instances of a lane keep their LDS reads in flight together)
+template <u32 NW>  // NW > 0: compile-time record width; 0: P.nw
+__device__ __forceinline__ u128x record_kmer_lds(const BriskParams& P, const u64* c, u32 n, u32 j) {
+    const u32 s = 2 * (n - 1 - j);
+    const u32 ws = s >> 6, bs = s & 63;
+    const u32 last = (NW ? NW : P.nw) - 1;
+    const u64 t0 = c[ws < last ? ws : last], t1 = c[ws + 1 < last ? ws + 1 : last], t2 = c[ws + 2 < last ? ws + 2 : last];
+    const u64 a0 = ws <= last ? t0 : 0, a1 = ws + 1 <= last ? t1 : 0, a2 = ws + 2 <= last ? t2 : 0;
+    u128x r;
+    r.lo = bs ? ((a0 >> bs) | (a1 << (64 - bs))) : a0;
+    r.hi = bs ? ((a1 >> bs) | (a2 << (64 - bs))) : a1;
+    return and128(r, mask128(2 * P.kb));
+}
+
+#define WI_BATCH 64u   // partitions a wave takes per work-counter atomic (same-address atomics serialise device-wide)
+
+// NI-instances-per-lane body of the expand + de-duplicate phases (NI = 4 when the
+// chunk has <= 256 instances, else 8: all NI instances of a lane are in flight together)
+template <u32 NI, u32 NW>
+__device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane, u32 ninst, u32 tsize, const u64* s_rec, const u32* s_pref,
+                                                  const uint8_t* s_irec, const u32* s_rmult, u64* s_key, u32* s_tab) {
+    u64 klo[NI], khi[NI];
+    u32 hh[NI], mult[NI];
+    u32 rix[NI];
+#pragma unroll
+    for (u32 it = 0; it < NI; it++) {
+        const u32 i = it * 64 + lane;
+        rix[it] = s_irec[i < ninst ? i : 0];
+    }
+#pragma unroll
+    for (u32 it = 0; it < NI; it++) {
+        const u32 i = it * 64 + lane;
+        const u32 r = rix[it];
+        const u64* c = s_rec + r * (NW ? NW + 1 : P.stride);
+        const u64 hdr = c[NW ? NW : P.nw];
+        const u32 j = i < ninst ? i - s_pref[r] : 0;
+        const u128x key = make_key(P, hdr_bucket(hdr), record_kmer_lds<NW>(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+        klo[it] = key.lo;
+        khi[it] = key.hi;
+        hh[it] = hash_key32(key) & (tsize - 1);
+        mult[it] = (s_rmult[r] & 0xffu) << WI_CNT_SHIFT;  // counts wrap at 256: so may the multiplicities
+        if (i < ninst) {
+            s_key[2 * i] = key.lo;
+            s_key[2 * i + 1] = key.hi;
+        }
+    }
+    wave_sync();
+    // de-duplicate: all of a lane's instances probe in lockstep rounds
+    u32 pending = 0;
+#pragma unroll
+    for (u32 it = 0; it < NI; it++)
+        if (it * 64 + lane < ninst) pending |= 1u << it;
+    while (__any(pending != 0)) {
+        u32 old[NI];
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            old[it] = EMPTY_SLOT;
+            if (pending >> it & 1) old[it] = atomicCAS(&s_tab[hh[it]], EMPTY_SLOT, (it * 64 + lane) | mult[it]);
+        }
+        u64 olo[NI], ohi[NI];
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            const u32 oi = old[it] == EMPTY_SLOT ? 0 : (old[it] & WI_IDX_MASK);
+            olo[it] = s_key[2 * oi];
+            ohi[it] = s_key[2 * oi + 1];
+        }
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            if (pending >> it & 1) {
+                if (old[it] == EMPTY_SLOT) {
+                    pending &= ~(1u << it);
+                } else if (olo[it] == klo[it] && ohi[it] == khi[it]) {
+                    atomicAdd(&s_tab[hh[it]], mult[it]);
+                    pending &= ~(1u << it);
+                } else {
+                    hh[it] = (hh[it] + 1) & (tsize - 1);
+                }
+            }
+        }
+    }
+}
+
+// Record-level de-duplication of the <= 64 records the lanes hold (also in s_rec): the first copy of every distinct record
+// survives, s_rmult[its lane] = the multiplicities of all its copies added up; returns whether this lane's record is a
+// later copy.  Header bits 48..55 carry a record's multiplicity (mod 256: counts wrap there anyway) once a partition's
+// records have been collapsed; they are not part of its identity.
+#define HDR_ID_MASK 0x0000ffffffffffffull
+__device__ __forceinline__ bool dedupe_records(u32 stride, const RecRegs& rr, u32 my_mult, u32 nrec, u32 lane, const u64* s_rec, u32* s_rtab, u32* s_rmult) {
+    s_rtab[lane] = EMPTY_SLOT;
+    s_rtab[lane + 64] = EMPTY_SLOT;
+    s_rmult[lane] = my_mult;
+    wave_sync();
+    bool dup = false;
+    if (lane < nrec) {
+        const u64 k1 = stride == 2 ? HDR_ID_MASK : ~0ull, k2 = stride == 3 ? HDR_ID_MASK : ~0ull, k3 = stride == 4 ? HDR_ID_MASK : ~0ull,
+                  k4 = stride == 5 ? HDR_ID_MASK : ~0ull;
+        const u64 w1 = rr.w1 & k1, w2 = rr.w2 & k2, w3 = rr.w3 & k3, w4 = rr.w4 & k4;
+        // a weak hash is enough for <= 64 records in 128 slots: rotate-xor fold, one 32-bit multiply
+        const u64 z = rr.w0 ^ ((w1 << 17) | (w1 >> 47)) ^ ((w2 << 31) | (w2 >> 33)) ^ ((w3 << 47) | (w3 >> 17)) ^ w4;
+        u32 h = ((((u32)z ^ (u32)(z >> 32)) * 0x9E3779B1u) >> 20) & (2 * WI_MAX_REC - 1);
+        for (;;) {
+            const u32 o = atomicCAS(&s_rtab[h], EMPTY_SLOT, lane);
+            if (o == EMPTY_SLOT) break;
+            const u64* oc = s_rec + o * stride;
+            bool same = oc[0] == rr.w0 && (oc[1] & k1) == w1;
+            if (stride > 2) same = same && (oc[2] & k2) == w2;
+            if (stride > 3) same = same && (oc[3] & k3) == w3;
+            if (stride > 4) same = same && (oc[4] & k4) == w4;
+            if (same) {
+                atomicAdd(&s_rmult[o], my_mult);
+                dup = true;
+                break;
+            }
+            h = (h + 1) & (2 * WI_MAX_REC - 1);
+        }
+    }
+    return dup;
+}
+
+// MAXI: k-mer instances per chunk.  256 (10 KB of LDS, 128 registers: 4 waves per SIMD) for the usual partitions of a
+// few hundred instances; 512 (2 waves per SIMD) when partitions are big -- few distinct minimizers, as with m <= 11 --
+// and the passes over a partition's entries saved by half as many chunks outweigh the occupancy.
+template <u32 MAXI>
+__device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
+                                            u32* __restrict__ work_counter) {
+    constexpr u32 TABLE = 2 * MAXI, TS = TABLE / 64, NI = MAXI / 64;
+    static_assert(MAXI % 256 == 0 && MAXI <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
+    __shared__ u64 s_key[2 * MAXI];
+    __shared__ u64 s_rec[WI_MAX_REC * 5 > MAXI / 2 ? WI_MAX_REC * 5 : MAXI / 2];
+    __shared__ u32 s_tab[TABLE];
+    __shared__ u32 s_pref[WI_MAX_REC + 1];
+    u32* s_list = (u32*)s_rec;  // [MAXI] the new entries' table words: built after the records have been expanded
+    __shared__ u32 s_rtab[2 * WI_MAX_REC];
+    __shared__ u32 s_rmult[WI_MAX_REC];
+    __shared__ __attribute__((aligned(4))) uint8_t s_irec[MAXI];
+    __shared__ u32 s_bm[2];
+
+    const u32 lane = threadIdx.x;
+    unsigned long long acur = ix.slot_cur[blockIdx.x], aend = ix.slot_end[blockIdx.x], garbage = 0;
+    const u32 kbits = 2 * P.kb + 6;
+
+    for (;;) {
+        // ---- take the next batch of partitions (one atomic per WI_BATCH partitions)
+        u32 t0 = 0;
+        if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
+        t0 = __shfl(t0, 0, 64);
+        if (t0 >= n_touched) break;
+        const u32 t_end = min(t0 + WI_BATCH, n_touched);
+        PartDesc d = desc[t0];
+        RecRegs rr = load_rec_regs(P, rec, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane);
+
+        for (u32 t = t0; t < t_end; t++) {
+            // descriptor of the partition after this one: in flight while this one is processed
+            const u32 tn = t + 1;
+            PartDesc dn{};
+            if (tn < t_end) dn = desc[tn];
+            RecRegs rn{0, 0, 0, 0, 0};
+
+            const u32 part = d.part;
+            u32 r_end = d.r_begin + d.n_rec;
+            u32 n_exist = d.n_exist;
+            u32 inst_left = d.n_inst;  // instances not yet processed: bounds the final size
+            unsigned long long off = d.off;
+            u32 cap = d.cap;
+            u32 bm0 = 0, bm1 = 0;
+
+            // A partition of many records (one hot bucket) first collapses its records window by window, in place:
+            // the chunks below then see each distinct record of a window once, with its multiplicity in the header,
+            // and far fewer chunks -- each of which streams the partition's entries -- are needed.
+            // (only in the big-partition kernel: the usual one is 2-3 % slower with this path compiled in)
+            bool collapsed = false;
+            if (MAXI > WI_MAX_INST && d.n_rec > 2 * WI_MAX_REC) {
+                u32 wr = d.r_begin;
+                for (u32 rd = d.r_begin; rd < r_end; rd += WI_MAX_REC) {
+                    const u32 avail = min(r_end - rd, (u32)WI_MAX_REC);
+                    if (rd != d.r_begin) rr = load_rec_regs(P, rec, rd, avail, lane);
+                    wave_sync();
+                    if (lane < avail) {
+                        u64* dst = s_rec + lane * P.stride;
+                        dst[0] = rr.w0;
+                        dst[1] = rr.w1;
+                        if (P.stride > 2) dst[2] = rr.w2;
+                        if (P.stride > 3) dst[3] = rr.w3;
+                        if (P.stride > 4) dst[4] = rr.w4;
+                    }
+                    const bool dup = dedupe_records(P.stride, rr, 1u, avail, lane, s_rec, s_rtab, s_rmult);
+                    wave_sync();
+                    const bool keep = lane < avail && !dup;
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {  // survivors move to the front of the partition's records (never past what is still to be read)
+                        u64* dst = rec + (u64)(wr + (u32)__popcll(bal & lanes_below(lane))) * P.stride;
+                        const u64 mult = (u64)(s_rmult[lane] & 0xffu) << 48;
+                        dst[0] = rr.w0;
+                        dst[1] = P.stride == 2 ? rr.w1 | mult : rr.w1;
+                        if (P.stride > 2) dst[2] = P.stride == 3 ? rr.w2 | mult : rr.w2;
+                        if (P.stride > 3) dst[3] = P.stride == 4 ? rr.w3 | mult : rr.w3;
+                        if (P.stride > 4) dst[4] = rr.w4 | mult;
+                    }
+                    wr += (u32)__popcll(bal);
+                }
+                collapsed = true;
+                r_end = wr;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the chunks read what was just written: same wave, same CU
+                rr = load_rec_regs(P, rec, d.r_begin, min(r_end - d.r_begin, (u32)WI_MAX_REC), lane);
+            }
+
+            for (u32 rc = d.r_begin; rc < r_end;) {
+                // ---- pick the chunk: up to WI_MAX_REC records / MAXI instances
+                const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
+                if (rc != d.r_begin) rr = load_rec_regs(P, rec, rc, avail, lane);
+                wave_sync();
+                if (lane < avail) {
+                    u64* dst = s_rec + lane * P.stride;
+                    dst[0] = rr.w0;
+                    dst[1] = rr.w1;
+                    if (P.stride > 2) dst[2] = rr.w2;
+                    if (P.stride > 3) dst[3] = rr.w3;
+                    if (P.stride > 4) dst[4] = rr.w4;
+                }
+                const u64 my_hdr = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
+                const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
+                const u32 my_mult = collapsed ? (u32)(my_hdr >> 48) & 0xffu : 1u;
+                const u32 x0 = wave_incl_scan(raw_n, lane);
+                // First try every available record: identical records (the same super-k-mer seen in
+                // several reads) collapse into one with a multiplicity, so far more raw instances fit.
+                // If the collapsed chunk is still too big, shrink to the prefix whose collapsed count fits (counted
+                // again on its own it can come out a little higher, once the first copy of a record lies beyond
+                // it: hence the loop), at the latest to the raw-count prefix, which always fits.
+                const u32 rawfit = (u32)__popcll(__ballot(lane < avail && x0 <= MAXI));  // >= 1; a prefix: x0 is monotone
+                u32 nrec = avail, my_n = 0, x = 0, ninst = 0;
+                for (int attempt = 0;; attempt++) {
+                    const bool dup = dedupe_records(P.stride, rr, my_mult, nrec, lane, s_rec, s_rtab, s_rmult);
+                    my_n = (lane < nrec && !dup) ? raw_n : 0;
+                    x = wave_incl_scan(my_n, lane);
+                    ninst = __shfl(x, 63, 64);
+                    if (ninst <= MAXI) break;
+                    const u32 fit = (u32)__popcll(__ballot(lane < nrec && x <= MAXI));  // x is monotone too
+                    nrec = (attempt >= 2 || fit <= rawfit) ? rawfit : min(fit, nrec - 1);
+                    wave_sync();
+                }
+                const u32 raw_inst = __shfl(x0, nrec - 1, 64);
+                u32 tsize = 128;
+                while (tsize < 2 * ninst && tsize < TABLE) tsize <<= 1;
+                s_pref[lane + 1] = x;
+                if (lane == 0) s_pref[0] = 0;
+#pragma unroll
+                for (u32 w = 0; w < TS; w++)
+                    if (w * 64 < tsize) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                {
+                    // instance -> record: each record marks its first instance, a running maximum spreads the marks
+                    // (records lie in lane order).  Every lane owns MAXI/64 consecutive instances here.
+                    u32* irec32 = (u32*)s_irec;
+#pragma unroll
+                    for (u32 q = 0; q < MAXI / 256; q++) irec32[q * 64 + lane] = 0;
+                    wave_sync();
+                    if (my_n) s_irec[x - my_n] = (uint8_t)(lane + 1);
+                    wave_sync();
+                    u32 wv[MAXI / 256], run = 0;
+#pragma unroll
+                    for (u32 q = 0; q < MAXI / 256; q++) {
+                        wv[q] = irec32[lane * (MAXI / 256) + q];
+                        run = op_max_u32(run, op_max_u32(op_max_u32(wv[q] & 0xff, (wv[q] >> 8) & 0xff), op_max_u32((wv[q] >> 16) & 0xff, wv[q] >> 24)));
+                    }
+                    u32 carry = wave_prev_lane(wave_incl_max_scan(run));  // the last mark before this lane's instances
+#pragma unroll
+                    for (u32 q = 0; q < MAXI / 256; q++) {
+                        const u32 b0 = op_max_u32(carry, wv[q] & 0xff), b1 = op_max_u32(b0, (wv[q] >> 8) & 0xff);
+                        const u32 b2 = op_max_u32(b1, (wv[q] >> 16) & 0xff), b3 = op_max_u32(b2, wv[q] >> 24);
+                        carry = b3;
+                        // marks are lane + 1; instances past the last record (none are read) may hold 0 - 1
+                        irec32[lane * (MAXI / 256) + q] = ((b0 - 1) & 0xff) | (((b1 - 1) & 0xff) << 8) | (((b2 - 1) & 0xff) << 16) | ((b3 - 1) << 24);
+                    }
+                }
+                wave_sync();
+                // the next partition's first records: requested now, consumed next iteration
+                if (rc == d.r_begin && tn < t_end) rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
+
+                // ---- 0/1. expand to entry keys and de-duplicate
+                if (P.nw == 3) {  // k63/m21/b14 and neighbours: compile-time record width
+                    if (ninst <= 64) expand_and_dedupe<1, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (ninst <= 128) expand_and_dedupe<2, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (ninst <= 192) expand_and_dedupe<3, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else expand_and_dedupe<NI, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                } else {
+                    if (ninst <= 128) expand_and_dedupe<2, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                    else expand_and_dedupe<NI, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                }
+                wave_sync();
+
+                // ---- 2. existing entries probe the table.  After the first chunk they include what this wave
+                // appended itself: same wave, same CU, so those stores only have to be complete (workgroup
+                // scope; __threadfence() would write back and invalidate the XCD's whole L2), and waiting
+                // for them here rather than at the end of the last chunk hides them behind phases 0 and 1.
+                if (rc != d.r_begin) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                // Four strides of entries at a time: their key and count loads are in flight together (a big partition
+                // of a hot bucket streams thousands of entries per chunk; one dependent load per stride was most
+                // of this kernel's time at k31/b11).
+                for (u32 e0 = 0; e0 < n_exist; e0 += 4 * 64) {
+                    u64 klo[4], khi[4];
+                    uint8_t cnt[4];
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 e = e0 + q * 64 + lane;
+                        const unsigned long long at = off + (e < n_exist ? e : 0);
+                        klo[q] = ix.keys[2 * at];
+                        khi[q] = ix.keys[2 * at + 1];
+                        cnt[q] = ix.counts[at];
+                    }
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 e = e0 + q * 64 + lane;
+                        if (e >= n_exist) continue;
+                        u32 h = hash_key32(mk128(klo[q], khi[q])) & (tsize - 1);
+                        for (;;) {
+                            const u32 v = s_tab[h];
+                            if (v == EMPTY_SLOT) break;
+                            const u32 i = v & WI_IDX_MASK;
+                            if (s_key[2 * i] == klo[q] && s_key[2 * i + 1] == khi[q]) {
+                                ix.counts[off + e] = (uint8_t)(cnt[q] + ((v & ~MATCHED_BIT) >> WI_CNT_SHIFT));
+                                s_tab[h] = v | MATCHED_BIT;
+                                break;
+                            }
+                            h = (h + 1) & (tsize - 1);
+                        }
+                    }
+                }
+                wave_sync();
+
+                // ---- 3. append the unmatched ones: compact them in LDS, then write them out with
+                // full waves (a store instruction costs the same with 3 active lanes as with 64)
+                u32 n_new = 0;
+#pragma unroll
+                for (u32 w = 0; w < TS; w++) {
+                    if (w * 64 < tsize) {
+                        const u32 v = s_tab[w * 64 + lane];
+                        const bool is_new = v != EMPTY_SLOT && !(v & MATCHED_BIT);
+                        const unsigned long long bal = __ballot(is_new);
+                        if (is_new) s_list[n_new + (u32)__popcll(bal & lanes_below(lane))] = v;
+                        n_new += (u32)__popcll(bal);
+                    }
+                }
+                wave_sync();
+                inst_left -= raw_inst;
+                if (n_exist + n_new > cap) {
+                    // move to a fresh slice, sized so that this partition moves at most once per batch
+                    const unsigned long long want = grow_cap(n_exist + n_new + inst_left);
+                    unsigned long long noff;
+                    if (want > ARENA_CHUNK / 8) {
+                        // a large slice goes straight to the global cursor: the private chunk never strands more
+                        // than a small request (< ARENA_CHUNK/8) at a refill, which the host's reserve covers
+                        unsigned long long got = 0;
+                        if (lane == 0) got = atomicAdd(ix.cursor, want);
+                        noff = __shfl(got, 0, 64);
+                    } else {
+                        if (acur + want > aend) {  // private chunk exhausted: abandon its tail, take a new one
+                            garbage += aend - acur;
+                            unsigned long long got = 0;
+                            if (lane == 0) got = atomicAdd(ix.cursor, (unsigned long long)ARENA_CHUNK);
+                            acur = __shfl(got, 0, 64);
+                            aend = acur + ARENA_CHUNK;
+                        }
+                        noff = acur;
+                        acur += want;
+                    }
+                    if (noff + want > ix.arena_cap || ninst > MAXI) {  // must not happen (host reserves the bound): drop, flag
+                        if (lane == 0) atomicOr(ix.err, ninst > MAXI ? 4u : 2u);
+                        break;
+                    }
+                    garbage += cap;
+                    cap = (u32)want;
+                    for (u32 e = lane; e < n_exist; e += 64) {
+                        ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
+                        ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (off + e) + 1];
+                        ix.counts[noff + e] = ix.counts[off + e];
+                    }
+                    off = noff;
+                }
+                for (u32 q = lane; q < n_new; q += 64) {
+                    const u32 v = s_list[q];
+                    const u32 i = v & WI_IDX_MASK;
+                    const u64 klo2 = s_key[2 * i], khi2 = s_key[2 * i + 1];
+                    const unsigned long long at = off + n_exist + q;
+                    ix.keys[2 * at] = klo2;
+                    ix.keys[2 * at + 1] = khi2;
+                    ix.counts[at] = (uint8_t)(v >> WI_CNT_SHIFT);
+                    // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here)
+                    const u32 bl = P.shift ? ((u32)shr128(mk128(klo2, khi2), kbits).lo & ((1u << P.shift) - 1)) : 0;
+                    const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;  // 64 bins at most
+                    if (bb < 32) bm0 |= 1u << bb; else bm1 |= 1u << (bb - 32);
+                }
+                n_exist += n_new;
+                rc += nrec;
+
+            }
+            if (P.shift <= 6) {  // OR the lanes' bucket bits together through LDS
+                if (lane < 2) s_bm[lane] = 0;
+                wave_sync();
+                if (bm0) atomicOr(&s_bm[0], bm0);
+                if (bm1) atomicOr(&s_bm[1], bm1);
+                wave_sync();
+                bm0 = s_bm[0];
+                bm1 = s_bm[1];
+            }
+            if (lane == 0) ix.dir[part] = DirEnt{off, n_exist, cap};
+            // bucket occupancy bits: exact when a partition holds <= 64 buckets (shift <= 6);
+            // partitions of more buckets are handled by k_bucket_bits below
+            if (P.shift <= 6 && lane < 2) {
+                const u32 mask = lane == 0 ? bm0 : bm1;
+                const u32 nb = 1u << P.shift;  // buckets per partition
+                const u64 first = ((u64)part << P.shift) >> P.ext_bits;  // ext_bits > 0 => shift == 0: the one bucket this partition is a slice of
+                // a bit that is already set needs no atomic: with few buckets (small b) every partition of a bucket
+                // would otherwise hit the same word, and same-address atomics serialise device-wide
+                if (mask) {
+                    if (nb >= 32) {
+                        if (lane * 32 < nb && (ix.bucket_bits[(first >> 5) + lane] & mask) != mask) atomicOr(&ix.bucket_bits[(first >> 5) + lane], mask);
+                    } else if (lane == 0) {
+                        const u32 bits = mask << (first & 31);
+                        if ((ix.bucket_bits[first >> 5] & bits) != bits) atomicOr(&ix.bucket_bits[first >> 5], bits);
+                    }
+                }
+            }
+            d = dn;
+            rr = rn;
+        }
+    }
+    if (lane == 0) {
+        ix.slot_cur[blockIdx.x] = acur;
+        ix.slot_end[blockIdx.x] = aend;
+        if (garbage) atomicAdd(&ix.stats[3], garbage);
+    }
+}
+
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+                                               u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
+    insert_body<WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+                                                                                         u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
+    insert_body<2 * WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
+}
+
+// bucket occupancy for partitions wider than 64 buckets (small part_bits): one pass over all entries
+__global__ void __launch_bounds__(256) k_bucket_bits(BriskParams P, IndexDev ix, u32 n_parts) {
+    const u32 kbits = 2 * P.kb + 6;
+    for (u32 part = blockIdx.x; part < n_parts; part += gridDim.x) {
+        const u32 cnt = ix.dir[part].cnt;
+        const unsigned long long off = ix.dir[part].off;
+        for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+            const u32 bucket = (part << P.shift) | ((u32)shr128(key, kbits).lo & ((1u << P.shift) - 1));
+            const u32 bit = 1u << (bucket & 31);
+            if (!(ix.bucket_bits[bucket >> 5] & bit)) atomicOr(&ix.bucket_bits[bucket >> 5], bit);
+        }
+    }
+}
+
+// stats(): nb_kmers = sum dir_cnt, largest = max dir_cnt, nb_buckets = popcount(bucket_bits)
+__global__ void __launch_bounds__(256) k_stats(const DirEnt* __restrict__ dir, u64 n_parts, const u32* __restrict__ bits, u64 n_words,
+                                               unsigned long long* out /* [0] kmers [1] buckets [2] largest */) {
+    __shared__ unsigned long long s_a[4], s_b[4], s_c[4];
+    unsigned long long a = 0, b = 0, c = 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_parts; i += stride) {
+        const u32 v = dir[i].cnt;
+        a += v;
+        c = v > c ? v : c;
+    }
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) b += __popc(bits[i]);
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+        const unsigned long long c2 = __shfl_down(c, o, 64);
+        c = c2 > c ? c2 : c;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = a;
+        s_b[threadIdx.x >> 6] = b;
+        s_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+        atomicAdd(&out[1], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        unsigned long long m = s_c[0];
+        for (int i = 1; i < 4; i++) m = s_c[i] > m ? s_c[i] : m;
+        atomicMax(&out[2], m);
+    }
+}

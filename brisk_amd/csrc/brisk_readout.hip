@@ -1,0 +1,310 @@
+// brisk_readout.hip -- reading the index: k_query, checksum, enumeration, look-ups, and the per-call upsert of the facade.
+// Included by brisk_kernels.hip (one translation unit).
+// ===========================================================================
+// k_query: k_insert's structure (one wave per partition, persistent waves, descriptors), but the
+// table keeps every k-mer instance in its own slot (equal keys sit behind each other in the probe
+// chain), the partition's entries stream through it, and every hit adds the entry's count to the
+// instance's record; a record's total goes to its read with one atomic
+// (get_superkmer, Brisk.hpp:102-118; summed per read as counter.cpp:296-301 does).
+__global__ void __launch_bounds__(64) k_query(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags,
+                                              const PartDesc* __restrict__ desc, u32 n_touched, IndexDev ix,
+                                              unsigned long long* __restrict__ per_read_sum, u32* __restrict__ work_counter) {
+    __shared__ u64 s_key[2 * WI_MAX_INST];
+    __shared__ u64 s_rec[WI_MAX_REC * 5];
+    __shared__ u32 s_tab[WI_TABLE];
+    __shared__ u32 s_pref[WI_MAX_REC + 1];
+    __shared__ u32 s_rsum[WI_MAX_REC];
+    __shared__ uint8_t s_irec[WI_MAX_INST];
+
+    const u32 lane = threadIdx.x;
+    for (;;) {
+        u32 t0 = 0;
+        if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
+        t0 = __shfl(t0, 0, 64);
+        if (t0 >= n_touched) break;
+        const u32 t_end = min(t0 + WI_BATCH, n_touched);
+        for (u32 t = t0; t < t_end; t++) {
+            const PartDesc d = desc[t];
+            if (d.n_exist == 0) continue;  // nothing to find in an empty partition
+            const u32 r_end = d.r_begin + d.n_rec;
+            for (u32 rc = d.r_begin; rc < r_end;) {
+                const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
+                const RecRegs rr = load_rec_regs(P, rec, rc, avail, lane);
+                wave_sync();
+                if (lane < avail) {
+                    u64* dst = s_rec + lane * P.stride;
+                    dst[0] = rr.w0;
+                    dst[1] = rr.w1;
+                    if (P.stride > 2) dst[2] = rr.w2;
+                    if (P.stride > 3) dst[3] = rr.w3;
+                    if (P.stride > 4) dst[4] = rr.w4;
+                }
+                const u64 my_hdr = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
+                const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
+                const u32 x0 = wave_incl_scan(raw_n, lane);
+                const u32 nrec = (u32)__popcll(__ballot(lane < avail && x0 <= WI_MAX_INST));  // >= 1; a prefix
+                const u32 my_n = lane < nrec ? raw_n : 0;
+                const u32 ninst = __shfl(x0, nrec - 1, 64);
+                s_pref[lane + 1] = x0;
+                if (lane == 0) s_pref[0] = 0;
+                s_rsum[lane] = 0;
+#pragma unroll
+                for (u32 w = 0; w < WI_TS; w++) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                {
+                    const u32 start = x0 - raw_n;
+                    for (u32 j = 0; j < my_n; j++) s_irec[start + j] = (uint8_t)lane;
+                }
+                wave_sync();
+                // expand and give every instance a slot of its own
+                for (u32 i = lane; i < ninst; i += 64) {
+                    const u32 r = s_irec[i];
+                    const u64* c = s_rec + r * P.stride;
+                    const u64 hdr = c[P.nw];
+                    const u32 j = i - s_pref[r];
+                    const u128x key = make_key(P, hdr_bucket(hdr), record_kmer_lds<0>(P, c, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+                    s_key[2 * i] = key.lo;
+                    s_key[2 * i + 1] = key.hi;
+                    u32 h = hash_key32(key) & (WI_TABLE - 1);
+                    while (atomicCAS(&s_tab[h], EMPTY_SLOT, i) != EMPTY_SLOT) h = (h + 1) & (WI_TABLE - 1);
+                }
+                wave_sync();
+                // the partition's entries look their key up; every instance holding it gets the count
+                for (u32 e = lane; e < d.n_exist; e += 64) {
+                    const u128x key = mk128(ix.keys[2 * (d.off + e)], ix.keys[2 * (d.off + e) + 1]);
+                    const u32 cnt = ix.counts[d.off + e];
+                    u32 h = hash_key32(key) & (WI_TABLE - 1);
+                    for (;;) {
+                        const u32 v = s_tab[h];
+                        if (v == EMPTY_SLOT) break;
+                        if (s_key[2 * v] == key.lo && s_key[2 * v + 1] == key.hi) atomicAdd(&s_rsum[s_irec[v]], cnt);
+                        h = (h + 1) & (WI_TABLE - 1);
+                    }
+                }
+                wave_sync();
+                if (lane < nrec) {
+                    const u32 sum = s_rsum[lane];
+                    if (sum) atomicAdd(&per_read_sum[tags[rc + lane]], (unsigned long long)sum);
+                }
+                rc += nrec;
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// k_enumerate: entries of partitions [p_begin, p_end) in order; out_base[p - p_begin]
+// is the exclusive prefix of dir_cnt over that range (Brisk::next yields unhashed k-mers).
+// order-independent digest of every entry (brisk_hip_checksum)
+__device__ __forceinline__ u64 fmix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_checksum(BriskParams P, IndexDev ix, u32 n_parts, unsigned long long* out) {
+    unsigned long long na = 0, sa = 0, da = 0;
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6, lane = threadIdx.x & 63;
+    for (u32 part = wave; part < n_parts; part += n_waves) {
+        const DirEnt de = ix.dir[part];
+        for (u32 e = lane; e < de.cnt; e += 64) {
+            const u128x key = mk128(ix.keys[2 * (de.off + e)], ix.keys[2 * (de.off + e) + 1]);
+            u32 idx;
+            u128x hk = entry_hashed_kmer(P, part, key, &idx);
+            const u64 mm = mix2m_inv(shr128(hk, 2 * idx).lo & P.m_mask, P.m_mask);
+            hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
+            const u32 cnt = ix.counts[de.off + e];
+            na += 1;
+            sa += cnt;
+            da += fmix(hk.lo ^ fmix(hk.hi ^ fmix(((u64)idx << 8) | cnt)));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        na += __shfl_xor(na, o, 64);
+        sa += __shfl_xor(sa, o, 64);
+        da += __shfl_xor(da, o, 64);
+    }
+    if (lane == 0 && na) {
+        atomicAdd(&out[0], na);
+        atomicAdd(&out[1], sa);
+        atomicAdd(&out[2], da);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dir_counts(const DirEnt* __restrict__ dir, u64 n, u32* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dir[i].cnt;
+}
+
+__global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u32 p_begin, u32 n_parts, const u64* __restrict__ out_base,
+                                                  u64* __restrict__ out_lo, u64* __restrict__ out_hi, uint8_t* __restrict__ out_idx,
+                                                  uint8_t* __restrict__ out_cnt, u32* __restrict__ out_id) {
+    const u32 pi = blockIdx.x;
+    if (pi >= n_parts) return;
+    const u32 part = p_begin + pi;
+    const u32 cnt = ix.dir[part].cnt;
+    const unsigned long long off = ix.dir[part].off;
+    const u64 ob = out_base[pi];
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+        u32 idx;
+        u128x hk = entry_hashed_kmer(P, part, key, &idx);
+        // unhash_kmer_minimizer (Kmers.cpp:178-187)
+        const u64 hm = shr128(hk, 2 * idx).lo & P.m_mask;
+        const u64 mm = mix2m_inv(hm, P.m_mask);
+        hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
+        out_lo[ob + e] = hk.lo;
+        out_hi[ob + e] = hk.hi;
+        out_idx[ob + e] = (uint8_t)idx;
+        out_cnt[ob + e] = ix.counts[off + e];
+        if (out_id) out_id[ob + e] = ix.ids[off + e];
+    }
+}
+
+// k_lookup: one wave per query (Brisk::get: hash the minimizer, find the bucket, compare compacted k-mers)
+__global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, const u64* __restrict__ q_lo, const u64* __restrict__ q_hi,
+                                                const uint8_t* __restrict__ q_idx, u64 n, uint8_t* __restrict__ out_data,
+                                                uint8_t* __restrict__ out_found, u32* __restrict__ out_id) {
+    const u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u32 lane = threadIdx.x & 63;
+    if (qi >= n) return;
+    const u32 idx = q_idx[qi];
+    u128x km = mk128(q_lo[qi], q_hi[qi]);
+    bool found = false;
+    u32 data = 0, id = 0;
+    if (idx <= P.w) {
+        const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
+        const u64 h = mix2m(mm, P.m_mask);
+        const u32 bucket = routing_id(P, h);
+        km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
+        const u32 cut = idx + P.suff_reduc;
+        const u128x lowm = mask128(2 * cut);
+        const u128x comp = or128(andn128(shr128(km, 2 * P.b), lowm), and128(km, lowm));
+        const u128x key = make_key(P, bucket, and128(comp, mask128(2 * P.kb)), cut);
+        const u32 part = bucket >> P.shift;
+        const u32 cnt = ix.dir[part].cnt;
+        const unsigned long long off = ix.dir[part].off;
+        for (u32 e = lane; e < cnt && !found; e += 64) {
+            if (ix.keys[2 * (off + e)] == key.lo && ix.keys[2 * (off + e) + 1] == key.hi) {
+                found = true;
+                data = ix.counts[off + e];
+                if (out_id) id = ix.ids[off + e];
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(found);
+    if (bal) {
+        const int src = __ffsll((long long)bal) - 1;
+        data = __shfl(data, src, 64);
+        id = __shfl(id, src, 64);
+    }
+    if (lane == 0) {
+        out_found[qi] = bal ? 1 : 0;
+        out_data[qi] = (uint8_t)data;
+        if (out_id) out_id[qi] = bal ? id : 0xffffffffu;
+    }
+}
+
+// ---- the per-call API of the facade (Brisk::insert_superkmer, Brisk.hpp:123-147) ----
+// entry key, partition and bucket of an UNHASHED (kmer_s, minimizer_idx): hash the minimizer
+// (Kmers.cpp:191-200), pick the bucket (Brisk.hpp:135-137), drop its nts (Kmers.cpp:138-145)
+__device__ __forceinline__ u128x key_of_kmer(const BriskParams& P, u128x km, u32 idx, u32* part, u32* bucket_out) {
+    const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
+    const u64 h = mix2m(mm, P.m_mask);
+    const u32 bucket = routing_id(P, h);
+    km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
+    const u32 cut = idx + P.suff_reduc;
+    const u128x lowm = mask128(2 * cut);
+    const u128x comp = or128(andn128(shr128(km, 2 * P.b), lowm), and128(km, lowm));
+    *part = bucket >> P.shift;
+    *bucket_out = bucket >> P.ext_bits;  // the bucket id proper (for the occupancy bitmap)
+    return make_key(P, bucket, and128(comp, mask128(2 * P.kb)), cut);
+}
+
+// find-all then insert-missing for the k-mers of ONE vector, in order (DenseMenuYo.hpp:248-310).
+// One wave; every k-mer scans its partition with 64 lanes.  Entry-id mode: a new entry takes
+// the next dense id; DATA lives with the caller, indexed by id.  Stops (and reports how many
+// k-mers it handled) when the arena cannot hold a move; the host grows it and calls again.
+__global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const u64* __restrict__ q_lo, const u64* __restrict__ q_hi,
+                                               const uint8_t* __restrict__ q_idx, u32 n, u32* __restrict__ out_id, uint8_t* __restrict__ out_new,
+                                               unsigned long long* __restrict__ id_counter, u32* __restrict__ n_done) {
+    const u32 lane = threadIdx.x;
+    u32 done = 0;
+    for (u32 qi = 0; qi < n; qi++) {
+        const u32 idx = q_idx[qi];
+        u32 part, bucket;
+        const u128x key = key_of_kmer(P, mk128(q_lo[qi], q_hi[qi]), idx <= P.w ? idx : 0, &part, &bucket);
+        DirEnt de = ix.dir[part];
+        bool found = false;
+        u32 id = 0;
+        for (u32 e = lane; e < de.cnt && !found; e += 64) {
+            if (ix.keys[2 * (de.off + e)] == key.lo && ix.keys[2 * (de.off + e) + 1] == key.hi) {
+                found = true;
+                id = ix.ids[de.off + e];
+            }
+        }
+        const unsigned long long bal = __ballot(found);
+        if (bal) {
+            id = __shfl(id, __ffsll((long long)bal) - 1, 64);
+            if (lane == 0) {
+                out_id[qi] = id;
+                out_new[qi] = 0;
+            }
+        } else {
+            if (de.cnt == de.cap) {  // move the partition to a larger slice
+                const u32 want = grow_cap(de.cnt + 1);
+                unsigned long long noff = 0;
+                if (lane == 0) noff = atomicAdd(ix.cursor, (unsigned long long)want);
+                noff = __shfl(noff, 0, 64);
+                if (noff + want > ix.arena_cap) {  // host must grow the arena; nothing was changed for this k-mer
+                    if (lane == 0) atomicAdd(ix.cursor, (unsigned long long)(0ull - want));
+                    break;
+                }
+                for (u32 e = lane; e < de.cnt; e += 64) {
+                    ix.keys[2 * (noff + e)] = ix.keys[2 * (de.off + e)];
+                    ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (de.off + e) + 1];
+                    ix.counts[noff + e] = ix.counts[de.off + e];
+                    ix.ids[noff + e] = ix.ids[de.off + e];
+                }
+                if (lane == 0) atomicAdd(&ix.stats[3], (unsigned long long)de.cap);
+                de.off = noff;
+                de.cap = want;
+            }
+            if (lane == 0) {
+                const u32 nid = (u32)atomicAdd(id_counter, 1ull);
+                const unsigned long long at = de.off + de.cnt;
+                ix.keys[2 * at] = key.lo;
+                ix.keys[2 * at + 1] = key.hi;
+                ix.counts[at] = 0;
+                ix.ids[at] = nid;
+                ix.dir[part] = DirEnt{de.off, de.cnt + 1, de.cap};
+                if (!(ix.bucket_bits[bucket >> 5] >> (bucket & 31) & 1u)) atomicOr(&ix.bucket_bits[bucket >> 5], 1u << (bucket & 31));
+                out_id[qi] = nid;
+                out_new[qi] = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the next k-mer of the vector reads this partition again (same wave)
+        }
+        done = qi + 1;
+    }
+    if (lane == 0) *n_done = done;
+}
+
+// records -> the k-mers of each vector, unhashed (what SuperKmerEnumerator::next hands out):
+// one wave per record, one lane per k-mer; out row r holds up to `row` k-mers
+__global__ void __launch_bounds__(64) k_expand_records(BriskParams P, const u64* __restrict__ rec, u32 n_rec, u32 row, u64* __restrict__ out_lo,
+                                                       u64* __restrict__ out_hi, uint8_t* __restrict__ out_idx) {
+    const u32 r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_rec) return;
+    const u64* c = rec + (u64)r * P.stride;
+    const u64 hdr = c[P.nw];
+    const u32 n = hdr_n(hdr);
+    if (lane >= n) return;
+    const u32 bucket = hdr_bucket(hdr);
+    const u128x key = make_key(P, bucket, record_kmer(P, c, n, lane), hdr_idx0(hdr) + lane);
+    u32 idx;
+    u128x hk = entry_hashed_kmer(P, bucket >> P.shift, key, &idx);
+    const u64 hm = shr128(hk, 2 * idx).lo & P.m_mask;
+    const u64 mm = mix2m_inv(hm, P.m_mask);
+    hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
+    out_lo[(u64)r * row + lane] = hk.lo;
+    out_hi[(u64)r * row + lane] = hk.hi;
+    out_idx[(u64)r * row + lane] = (uint8_t)idx;
+}

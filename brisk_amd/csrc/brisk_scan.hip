@@ -1,0 +1,829 @@
+// brisk_scan.hip -- reads in: packing, synthetic reads, the super-k-mer scan (k_scan, k_scan2) and the chunk machinery
+// for long sequences.  Included by brisk_kernels.hip (one translation unit).
+// ===========================================================================
+// ASCII -> 2-bit packed (nuc2int, Kmers.cpp:442-444), 16 bases per thread
+__global__ void __launch_bounds__(256) k_pack_ascii(const uint8_t* __restrict__ bases, u64 n_bases, u32* __restrict__ packed, u64 n_words) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const u64 base = w * 16;
+    u32 v = 0;
+    if (base + 16 <= n_bases && ((uintptr_t)(bases + base) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(bases + base);
+        const u32 ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v = (v << 2) | ((ws[i] >> (8 * j + 1)) & 3u);
+        }
+    } else {
+        for (int i = 0; i < 16; i++) {
+            const u64 p = base + i;
+            const u32 c = p < n_bases ? ((bases[p] >> 1) & 3u) : 0u;
+            v = (v << 2) | c;
+        }
+    }
+    packed[w] = v;
+}
+
+// ===========================================================================
+// synthetic reads: splitmix64 n-th output; written packed.
+__device__ __forceinline__ u64 sm_mix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 sm_u(u64 s, u64 i) { return sm_mix(s + (i + 1) * 0x9E3779B97F4A7C15ull); }
+// genome letter index 0..3 = "ACGT" -> 2-bit code A0 C1 T2 G3
+__device__ __forceinline__ u32 acgt_to_code(u32 i) { return i == 2 ? 3u : i == 3 ? 2u : i; }
+
+// one thread per output word (16 nts) of the packed stream of fixed-length reads
+__global__ void __launch_bounds__(256) k_synth(u64 genome_len, u64 first_read, u64 n_reads, u32 L, u64 seed_g, u64 seed_r,
+                                               u32* __restrict__ packed, u64 n_words, u64* __restrict__ starts) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w <= n_reads) starts[w] = w * (u64)L;
+    if (w >= n_words) return;
+    const u64 total = n_reads * (u64)L;
+    u32 v = 0;
+    u64 cur_read = ~0ull, p = 0;
+    u32 strand = 0;
+    for (int i = 0; i < 16; i++) {
+        const u64 q = w * 16 + i;
+        u32 c = 0;
+        if (q < total) {
+            const u64 r = q / L;
+            const u32 off = (u32)(q - r * L);
+            if (r != cur_read) {
+                cur_read = r;
+                const u64 rid = first_read + r;
+                p = sm_u(seed_r, 2 * rid) % (genome_len - L + 1);
+                strand = (u32)(sm_u(seed_r, 2 * rid + 1) >> 63);
+            }
+            if (!strand)
+                c = acgt_to_code((u32)(sm_u(seed_g, p + off) >> 62));
+            else
+                c = acgt_to_code((u32)(sm_u(seed_g, p + L - 1 - off) >> 62)) ^ 2u;
+        }
+        v = (v << 2) | c;
+    }
+    packed[w] = v;
+}
+
+// out[0] = sum over reads of max(0, len-k+1): the number of k-mer instances (an upper bound on records);
+// out[1] = the share of it in reads of more than 1024 k-mers (a record every ~(w+2)/2 k-mers there, while a
+// short read makes a few records whatever its length).  One atomic pair per block.
+__global__ void __launch_bounds__(256) k_count_kmers(const u64* __restrict__ starts, u64 n_reads, u32 k, unsigned long long* out) {
+    __shared__ unsigned long long s_sum[4], s_long[4];
+    unsigned long long acc = 0, lng = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
+        const u64 len = starts[r + 1] - starts[r];
+        if (len >= k) {
+            acc += len - k + 1;
+            if (len - k + 1 > 1024) lng += len - k + 1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        lng += __shfl_down(lng, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[threadIdx.x >> 6] = acc;
+        s_long[threadIdx.x >> 6] = lng;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(out, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        const unsigned long long l = s_long[0] + s_long[1] + s_long[2] + s_long[3];
+        if (l) atomicAdd(out + 1, l);
+    }
+}
+
+// ===========================================================================
+// k_scan v1: one lane per read runs the enumerator state machine of
+// Kmers.cpp:509-603 exactly; each closed super-k-mer becomes one record.
+struct ScanOut {
+    u64* rec;                    // cap * stride words
+    u64 cap;
+    unsigned long long* n_rec;   // record cursor
+    unsigned long long* hist;    // per partition: low 32 records, high 32 k-mer instances (may be null)
+    u32* overflow;
+    u32* tag;                    // query mode: read index per record; sequence mode: position of the first k-mer (may be null)
+    u64* ret;                    // sequence mode: the minimizer value next() returns with the vector (may be null)
+};
+
+struct MiniState {
+    u64 mini;
+    u32 pos;
+    bool rev;
+};
+
+// get_minimizer (Kmers.cpp:367-408) of the K-mer at stream nts [q, q+K): the
+// re-scan runs over the LOW 64 BITS of the k-mer only (line 371, F2).
+__device__ MiniState rescan_minimizer(const u32* __restrict__ packed, u64 q, u32 K, u32 m, u64 M, const double* coef) {
+    const u32 nlow = K < 32 ? K : 32;
+    const u64 low = load_nts(packed, q + K - nlow, nlow);
+    u64 cur = low;
+    u64 fwd = cur & M;
+    u64 rc = rc64(fwd, m);
+    MiniState s;
+    s.mini = fwd < rc ? fwd : rc;
+    s.rev = s.mini != fwd;
+    s.pos = 0;
+    u64 best = order_key(s.mini, m, M, coef);
+    int canon = -1;  // canonized(seq,K), evaluated on first use
+    for (u32 i = 1; i <= K - m; i++) {
+        cur >>= 2;
+        fwd = cur & M;
+        rc = rc64(fwd, m);
+        const u64 c = fwd < rc ? fwd : rc;
+        const u64 h = order_key(c, m, M, coef);
+        if (h < best) {
+            s.pos = i;
+            s.mini = c;
+            s.rev = c != fwd;
+            best = h;
+        } else if (h == best) {
+            const u32 d = K - m - i;
+            if (d < s.pos) {
+                s.pos = d;
+                s.mini = c;
+                s.rev = c != fwd;
+            } else if (d == s.pos) {
+                if (canon < 0) {
+                    const u64 hi = K > 32 ? load_nts(packed, q, K - 32) : 0;
+                    canon = canonized_as_executed(mk128(low, hi), K) ? 1 : 0;
+                }
+                if (!canon) {
+                    s.pos = d;
+                    s.mini = c;
+                    s.rev = false;
+                }
+            }
+        }
+    }
+    return s;
+}
+
+// Build and append the record of one super-k-mer: k-mers at read positions
+// [p0, p0+n), vector reversed if `rev` (Kmers.cpp:554-556,597-599); idx_end is
+// the minimizer_idx of the LAST element of the returned vector.
+__device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
+                               u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
+    if (slot >= out.cap) {
+        *out.overflow = 1;
+        return;
+    }
+    const u32 L = P.k + n - 1;
+    W4 S = load_span(packed, q0 + p0, L);
+    if (rev) S = w4_rc(S, L);
+    // minimizer of every k-mer of the vector = the m-mer at suffix offset idx_end
+    // of the last one (hash_kmer_minimizer_inplace re-extracts it, Kmers.cpp:191-200)
+    const u64 mm = w4_shr(S, 2 * idx_end).w0 & P.m_mask;
+    const u64 h = mix2m(mm, P.m_mask);
+    const u32 bucket = routing_id(P, h);  // Brisk.hpp:135-137, plus the extra routing bits
+    // replace the minimizer by its hash (replace_slice, Kmers.cpp:149-159)
+    const W4 hole = w4_shl(W4{P.m_mask, 0, 0, 0}, 2 * idx_end);
+    S = w4_or(w4_andn(S, hole), w4_shl(W4{h, 0, 0, 0}, 2 * idx_end));
+    // drop the b bucket nts at suffix offset idx_end + suff_reduc (get_compacted, Kmers.cpp:138-145)
+    const u32 cut = idx_end + P.suff_reduc;
+    const W4 lowm = w4_mask(2 * cut);
+    const W4 C = w4_or(w4_andn(w4_shr(S, 2 * P.b), lowm), w4_and(S, lowm));
+
+    u64* r = out.rec + slot * P.stride;
+    r[0] = C.w0;
+    if (P.nw > 1) r[1] = C.w1;
+    if (P.nw > 2) r[2] = C.w2;
+    if (P.nw > 3) r[3] = C.w3;
+    const u32 idx0p = idx_end - (n - 1) + P.suff_reduc;
+    r[P.nw] = rec_header(bucket, n, idx0p);
+    if (out.tag) out.tag[slot] = tag;
+    if (out.ret) out.ret[slot] = ret;
+    if (out.hist) atomicAdd(&out.hist[bucket >> P.shift], 1ull | ((unsigned long long)n << 32));
+}
+__device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
+                            u32 idx_end, const ScanOut& out, u32 tag, u64 ret = 0) {
+    emit_record_at(P, packed, q0, p0, n, rev, idx_end, out, tag, ret, atomicAdd(out.n_rec, 1ull));
+}
+
+// query_mode: stop after the first super-k-mer whose returned minimizer is 0,
+// the first one excepted (counter.cpp:296-307)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan(BriskParams P, const u32* __restrict__ packed, const u64* __restrict__ starts,
+                                                     u64 n_reads, const double* __restrict__ g_coef, ScanOut out, int query_mode) {
+    __shared__ double s_coef[128];
+    for (u32 i = threadIdx.x; i < 4 * P.m; i += blockDim.x) s_coef[i] = g_coef[i];
+    __syncthreads();
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const u64 q0 = starts[r];
+    const u64 len = starts[r + 1] - q0;
+    const u32 k = P.k, m = P.m, w = P.w;
+    if (len < k) return;  // counter.cpp:233-235
+    const u64 M = P.m_mask;
+
+    // candidate m-mer state: bases [k-m-1, k-1), forward keeps m-1 of them (Kmers.cpp:531)
+    u64 cf = 0, cr = 0;
+    for (u32 i = 0; i < m; i++) {
+        const u32 c = nt_at(packed, q0 + k - m - 1 + i);
+        cf = ((cf << 2) + c) & (M >> 2);
+        cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
+    }
+    MiniState st = rescan_minimizer(packed, q0, k - 1, m, M, s_coef);  // Kmers.cpp:533
+    u64 mini_hash = order_key(st.mini, m, M, s_coef);
+    u32 mini_pos = st.pos;
+    bool reversed = st.rev;
+    u64 mini = st.mini;
+
+    const u32 nk = (u32)(len - k + 1);
+    u32 n = 0, p0 = 0, first_idx = 0, last_idx = 0, n_emitted = 0;
+    for (u32 p = 0; p < nk; p++) {
+        const u32 c = nt_at(packed, q0 + k - 1 + p);
+        cf = ((cf << 2) + c) & M;
+        cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
+        mini_pos++;
+        const u64 cand = cf < cr ? cf : cr;
+        const u64 h = order_key(cand, m, M, s_coef);
+        bool closed = false;
+        const bool old_rev = reversed;
+        u64 ret = 0;
+        if (mini_pos > w) {  // the minimizer left the k-mer (Kmers.cpp:551-562)
+            closed = true;
+            ret = mini;
+            st = rescan_minimizer(packed, q0 + p, k, m, M, s_coef);
+            mini = st.mini;
+            mini_pos = st.pos;
+            reversed = st.rev;
+            mini_hash = order_key(mini, m, M, s_coef);
+        } else if (h < mini_hash) {  // strictly smaller candidate (Kmers.cpp:564-577)
+            closed = true;
+            ret = mini;
+            mini_hash = h;
+            mini_pos = 0;
+            mini = cand;
+            reversed = cand == cr;
+        }
+        const u32 idx = reversed ? w - mini_pos : mini_pos;  // Kmers.cpp:578-584
+        if (closed && p > 0) {  // a close at p == 0 is ignored (Kmers.cpp:585-592)
+            if (query_mode && n_emitted > 0 && ret == 0) return;
+            emit_record(P, packed, q0, p0, n, old_rev, old_rev ? first_idx : last_idx, out, out.ret ? p0 : (u32)r, ret);
+            n_emitted++;
+            n = 0;
+        }
+        if (n == 0) {
+            p0 = p;
+            first_idx = idx;
+        }
+        last_idx = idx;
+        n++;
+    }
+    if (n > 0) {  // Kmers.cpp:596-601
+        if (query_mode && n_emitted > 0 && mini == 0) return;
+        emit_record(P, packed, q0, p0, n, reversed, reversed ? first_idx : last_idx, out, out.ret ? p0 : (u32)r, mini);
+    }
+}
+
+__device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1ull << lane) - 1; }
+
+// ===========================================================================
+// k_scan2: the production scan.  Same results as k_scan (kept above as the plain
+// restatement used for A/B), restructured for the wave:
+//   * one lane per read steps the candidate m-mer; its order key is a table-driven
+//     decycling class (4-nt chunk sums in LDS, exact fold only inside a 1e-9 guard
+//     band around +-eps) plus the integer mixer;
+//   * a re-scan (get_minimizer, Kmers.cpp:367-408) is done by a half-wave, one window per lane
+//     straight from the k-mer's low 64 bits (zero-padded "fake" windows included, F2), two
+//     k-mers per round, using the closed form of the tie rules (first and last position of
+//     the minimum key);
+//   * closed super-k-mers are queued in LDS and turned into records by full waves.
+struct ScanCfg {
+    u32 nlow;     // nts of a k-mer that get_minimizer sees: min(32, k)   (F2)
+    u32 nlow1;    // same for the (k-1)-mer
+    u32 nch;      // 4-nt chunks of a decycling sum: ceil((m-1)/4)
+    u32 qcap;     // emit queue entries per wave
+};
+
+// class from chunk tables: tabs[c][v] (R) and tabs[nch+c][v] (R of the rotation)
+template <int NCH>  // NCH > 0: compile-time chunk count (unrolled lookups); 0: runtime nch
+__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const double* tabs, const double* coef) {
+    double r = 0.0, rr = 0.0;
+    if (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+            rr += tabs[(NCH + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
+        }
+    } else {
+        for (u32 c = 0; c < nch; c++) {
+            r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+            rr += tabs[(nch + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
+        }
+    }
+    const double eps = 0.000001, g = 1e-9;
+    // any summation order is within ~1e-13 of the reference's fold; inside the guard band redo it exactly
+    if (fabs(fabs(r) - eps) < g || fabs(fabs(rr) - eps) < g) return decy_class(x, m, coef);
+    if (r > eps) return rr < eps ? 0u : 2u;
+    if (r < -eps) return rr > -eps ? 1u : 2u;
+    return 2u;
+}
+template <int NCH = 0>
+__device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, const double* tabs, const double* coef) {
+    return ((u64)decy_class_fast<NCH>(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
+}
+
+__global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, const double* __restrict__ g_tabs, const u64* __restrict__ x, u64 n,
+                                                    int exact, u64* __restrict__ out) {
+    extern __shared__ double smem_d[];
+    const u32 n_tab = 128 + 2 * nch * 256;
+    for (u32 i = threadIdx.x; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, smem_d + 128, smem_d);
+}
+
+// value of a wave-uniform lane, through SGPRs
+__device__ __forceinline__ u64 read_lane_u64(u64 v, int L) {
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, L), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), L);
+    return ((u64)hi << 32) | lo;
+}
+
+// ---- long sequences: scanned as overlapping chunks, each chunk a "virtual read" ----------------
+// The enumerator's state (minimizer key, its position, its strand) before a step depends on history, so a
+// chunk starts SCAN_WARMUP steps early from a fresh state, emits only the vectors that start inside its
+// own window [emit_from, emit_until), and exports the state it had reached at emit_from (spec); its
+// predecessor exports the state it had at the same step (truth).  Equal state + same nucleotides =>
+// identical stream from there on.  A chunk is EXACT when its predecessor is exact and the two states
+// match (the first chunk of a sequence is exact by definition); matching against a predecessor that is
+// itself wrong proves nothing (two cold starts can agree with each other inside a periodic region and
+// both be out of phase with the sequential run).  A chunk whose states do not match is scanned again
+// from its window's first step, SEEDED with the exact state its predecessor exported: no warm-up, no
+// speculation.  k_chunk_match / k_chunk_commit extend exactness along every sequence as far as it reaches and
+// list the chunks to re-scan; the host repeats until every chunk is exact (one round per mismatch along a
+// sequence: long runs without a new minimum -- homopolymers, short tandem repeats).
+#define SCAN_LONG 8192u     // sequences with more k-mers than this are chunked
+#define SCAN_WARMUP 512u    // steps a speculative chunk runs before its window
+struct VRead {
+    u64 q0;          // stream index of the virtual read's first nt
+    u32 len;         // nts
+    u32 emit_from;   // local step of the first vector start that belongs to this chunk
+    u32 emit_until;  // local step bound (exclusive); ~0u: to the end of the sequence
+    u32 read;        // index of the sequence in the batch
+    u32 flags;       // 1: first chunk of its sequence, 2: runs to the sequence's last k-mer, 4: seeded start
+    u32 slot;        // chunk index: where its states live, and the tag of its records
+    u32 first;       // chunk index of its sequence's first chunk
+    u32 pad;
+};
+struct ChunkState {
+    u64 hash;
+    u32 pos_rev;     // mini_pos | reversed << 31
+    u32 set;
+};
+struct ChunkCtl {
+    const VRead* vreads;   // null: whole reads from `starts`
+    ChunkState* spec;      // [n_chunks]   state a speculative chunk reached at its emit_from
+    ChunkState* truth;     // [n_chunks+1] state the previous chunk had at the same step; seed of a seeded chunk
+    u32 long_limit;        // whole-read launch: skip reads with more k-mers than this (0: none)
+};
+#define CHUNK_EXACT 1u      // chunk status bits
+#define CHUNK_RERUN 2u      // its speculative records are void, a seeded scan replaced them
+
+// plan the chunks of long reads (consecutive slots per read): one thread per read reserves the slots, then one
+// block per long read writes them (a chromosome is ~10^5 chunks)
+struct LongRead {
+    u32 read, base, n_chunks, pad;
+};
+__global__ void __launch_bounds__(256) k_plan_chunks(const u64* __restrict__ starts, u64 n_reads, u32 k, u32 chunk, u32 cap, u32* __restrict__ n_vreads,
+                                                     LongRead* __restrict__ longs, u32* __restrict__ n_long) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const u64 len = starts[r + 1] - starts[r];
+    if (len < k) return;
+    const u64 nk = len - k + 1;
+    if (nk <= SCAN_LONG) return;
+    const u32 nc = (u32)((nk + chunk - 1) / chunk);
+    const u32 base = atomicAdd(n_vreads, nc);
+    if (base + nc > cap) return;  // cannot happen: cap is the bound the host computed
+    longs[atomicAdd(n_long, 1u)] = LongRead{(u32)r, base, nc, 0u};
+}
+__global__ void __launch_bounds__(256) k_fill_chunks(const u64* __restrict__ starts, u32 k, u32 w, u32 chunk, const LongRead* __restrict__ longs, u32 n_long,
+                                                     VRead* __restrict__ vreads) {
+    for (u32 li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const LongRead lr = longs[li];
+        const u64 q0 = starts[lr.read], nk = starts[lr.read + 1] - q0 - k + 1;
+        for (u32 c = threadIdx.x; c < lr.n_chunks; c += blockDim.x) {
+            const u64 b0 = (u64)c * chunk, b1 = b0 + chunk;
+            const u64 s0 = c == 0 ? 0 : b0 - SCAN_WARMUP;
+            const bool last = b1 >= nk;
+            const u64 end_step = last ? nk : (b1 + w + 2 < nk ? b1 + w + 2 : nk);
+            VRead v;
+            v.q0 = q0 + s0;
+            v.len = (u32)(end_step - s0 + k - 1);
+            v.emit_from = (u32)(b0 - s0);
+            v.emit_until = last ? 0xffffffffu : (u32)(b1 - s0);
+            v.read = lr.read;
+            v.flags = (c == 0 ? 1u : 0u) | (end_step == nk ? 2u : 0u);
+            v.slot = lr.base + c;
+            v.first = lr.base;
+            v.pad = 0;
+            vreads[lr.base + c] = v;
+        }
+    }
+}
+// One round of the exactness walk, one thread per chunk (a single chromosome is ~10^5 chunks: no serial walk).
+// cursor[first] = first chunk of the sequence not yet known exact; stop[first] = first chunk at or after the
+// cursor whose speculative state does not match what its predecessor exported.  Chunks in [cursor, stop) are
+// exact by induction (each matches the export of an exact predecessor); chunk `stop` is queued for a seeded
+// re-scan from the exact state in truth[stop]; the walk resumes behind it in the next round.
+__global__ void __launch_bounds__(256) k_chunk_match(const VRead* __restrict__ vreads, const ChunkState* __restrict__ spec,
+                                                     const ChunkState* __restrict__ truth, u32 n_chunks, const u32* __restrict__ cursor,
+                                                     u32* __restrict__ stop) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks) return;
+    const u32 f = vreads[i].first;
+    const u32 c = cursor[f] > f + 1 ? cursor[f] : f + 1;
+    if (i < c) return;
+    const ChunkState a = spec[i], b = truth[i];
+    if (!(a.set && b.set && a.hash == b.hash && a.pos_rev == b.pos_rev)) atomicMin(&stop[f], i);
+}
+__global__ void __launch_bounds__(256) k_chunk_commit(const VRead* __restrict__ vreads, u32 n_chunks, u32 chunk, u32 k, u32 w,
+                                                      const u64* __restrict__ starts, const u32* __restrict__ cursor, const u32* __restrict__ stop,
+                                                      u32* __restrict__ status, VRead* __restrict__ rerun, u32* __restrict__ n_rerun) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks) return;
+    const VRead me = vreads[i];
+    const u32 f = me.first;
+    const u32 c = cursor[f] > f + 1 ? cursor[f] : f + 1;
+    const u32 st = stop[f];
+    if (i == f) status[i] |= CHUNK_EXACT;
+    if (i < c || i > st) return;
+    if (i < st) {
+        status[i] |= CHUNK_EXACT;
+        return;
+    }
+    // i == st: scan this chunk again from its window's first step, from the exact state in truth[i]
+    const u64 q0 = starts[me.read], nk = starts[me.read + 1] - q0 - k + 1;
+    const u64 b0 = (u64)(i - f) * chunk, b1 = b0 + chunk;
+    const bool last = b1 >= nk;
+    const u64 end_step = last ? nk : (b1 + w + 2 < nk ? b1 + w + 2 : nk);
+    VRead v;
+    v.q0 = q0 + b0;
+    v.len = (u32)(end_step - b0 + k - 1);
+    v.emit_from = 0;
+    v.emit_until = last ? 0xffffffffu : (u32)(b1 - b0);
+    v.read = me.read;
+    v.flags = 4u | (end_step == nk ? 2u : 0u);
+    v.slot = i;
+    v.first = f;
+    v.pad = 0;
+    rerun[atomicAdd(n_rerun, 1u)] = v;
+    status[i] = CHUNK_EXACT | CHUNK_RERUN;  // exact once the re-scan launched after this kernel has run
+}
+__global__ void __launch_bounds__(256) k_chunk_next(const VRead* __restrict__ vreads, u32 n_chunks, u32* __restrict__ cursor, u32* __restrict__ stop) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks || vreads[i].first != i) return;
+    cursor[i] = stop[i] == 0xffffffffu ? 0xffffffffu : stop[i] + 1;
+    stop[i] = 0xffffffffu;
+}
+// ---- a query over chunked sequences (query_sequence stops a sequence at the first super-k-mer, other than its
+// first, whose returned minimizer is 0, apps/counter.cpp:304-306).  Chunks cannot know what happened before them,
+// so they emit everything, every record carrying where its vector starts and whether its minimizer is 0
+// (ScanOut::ret); once the chunks are exact, k_query_break finds each sequence's stop and k_query_filter drops what
+// lies at or behind it, along with the speculative records of re-scanned chunks, and tags the rest with their read.
+__global__ void __launch_bounds__(256) k_query_break(const u64* __restrict__ ret, const u32* __restrict__ tags, u64 first, u64 n_spec_end, u64 n_rec,
+                                                     const VRead* __restrict__ vreads, const u32* __restrict__ status, const u64* __restrict__ starts,
+                                                     unsigned long long* __restrict__ brk) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const u32 slot = tags[i];
+    if (i < n_spec_end && (status[slot] & CHUNK_RERUN)) return;
+    const u64 r = ret[i], q = r & 0x7fffffffffffffffull;
+    const VRead v = vreads[slot];
+    if ((r >> 63) && q > starts[v.read]) atomicMin(&brk[v.first], (unsigned long long)q);
+}
+__global__ void __launch_bounds__(256) k_query_filter(BriskParams P, const u64* __restrict__ rec, const u64* __restrict__ ret, const u32* __restrict__ tags, u64 first,
+                                                      u64 n_spec_end, u64 n_rec, const VRead* __restrict__ vreads, const u32* __restrict__ status,
+                                                      const unsigned long long* __restrict__ brk, u64* __restrict__ out, u32* __restrict__ tag_out,
+                                                      unsigned long long* __restrict__ n_out) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const u32 slot = tags[i];
+    if (i < n_spec_end && (status[slot] & CHUNK_RERUN)) return;
+    const VRead v = vreads[slot];
+    if ((ret[i] & 0x7fffffffffffffffull) >= brk[v.first]) return;
+    const unsigned long long o = atomicAdd(n_out, 1ull);
+    for (u32 j = 0; j < P.stride; j++) out[o * P.stride + j] = rec[i * P.stride + j];
+    tag_out[o] = v.read;
+}
+// keep the speculative records of the chunks that were not re-scanned
+__global__ void __launch_bounds__(256) k_filter_records(BriskParams P, const u64* __restrict__ rec, const u32* __restrict__ tags, u64 first, u64 n_rec,
+                                                        const u32* __restrict__ status, u64* __restrict__ out, unsigned long long* __restrict__ n_out) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    if (status[tags[i]] & CHUNK_RERUN) return;
+    const unsigned long long slot = atomicAdd(n_out, 1ull);
+    for (u32 j = 0; j < P.stride; j++) out[slot * P.stride + j] = rec[i * P.stride + j];
+}
+
+// closed form of get_minimizer's fold (Kmers.cpp:377-405) given the first and last window
+// holding the minimum key, their `reversed` flags and K-m
+__device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first, bool rev_last, u32 Km, bool canon_if_needed_known, bool canon,
+                                             u32* pos, bool* rev, bool* need_canon) {
+    *need_canon = false;
+    *pos = first;
+    *rev = rev_first;
+    if (last != first) {
+        const u32 dT = Km - last;
+        if (dT < first) {
+            *pos = dT;
+            *rev = rev_last;
+        } else if (dT == first) {
+            if (!canon_if_needed_known) *need_canon = true;
+            else if (!canon) *rev = false;
+        }
+    }
+}
+
+// what is left in the waves' queues when their reads end: one slot reservation for the whole block
+__device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, const u64* q_start,
+                                                 const u32* q_misc, const u32* q_tag, u32 qcount, u32* s_wcnt, unsigned long long* s_wbase) {
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) s_wcnt[wid] = qcount;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
+        for (u32 i = 0; i < nw; i++) total += s_wcnt[i];
+        *s_wbase = total ? atomicAdd(out.n_rec, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = *s_wbase;
+    for (u32 i = 0; i < wid; i++) base += s_wcnt[i];
+    for (u32 e = lane; e < qcount; e += 64) {
+        const u32 mi = q_misc[e];
+        emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], q_start[e] | ((u64)((mi >> 17) & 1) << 63), base + e);
+    }
+}
+
+// MODE 0: reads, insert; 1: reads, query (stops a read at a returned minimizer of 0); 2: virtual reads (chunks of long sequences)
+// KK, MM: k and m as compile-time constants for the common parameter sets (0: from P) -- folds the shifts and masks and,
+// above all, frees scalar registers: the generic kernel spills 70+ of them into vector lanes and pays a v_readlane per use
+template <int NCH, int MODE, int KK, int MM>
+__global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
+                                                u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, ChunkCtl cc) {
+    constexpr bool VR = MODE == 2, query_mode = MODE == 1;
+    extern __shared__ double smem_d[];
+    double* s_coef = smem_d;             // 128
+    double* s_tabs = smem_d + 128;       // 2*nch*256
+    const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const u32 n_tab = 128 + 2 * (NCH ? (u32)NCH : cfg.nch) * 256;
+    for (u32 i = tid; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
+    unsigned long long* s_wbase = (unsigned long long*)(smem_d + n_tab);      // block's slot base at the final flush
+    u32* s_wcnt = (u32*)(s_wbase + 1);                                         // [16] records left per wave
+    u64* q_start = (u64*)(smem_d + n_tab + 9) + (size_t)wid * (2 * cfg.qcap);  // [qcap] stream index of the super-k-mer's first nt
+    u32* q_misc = (u32*)(q_start + cfg.qcap);      // [qcap] n | idx_end<<8 | rev<<16
+    u32* q_tag = q_misc + cfg.qcap;                // [qcap] read index
+    __syncthreads();
+
+    const u32 k = KK ? (u32)KK : P.k, m = MM ? (u32)MM : P.m, w = k - m, nch = NCH ? (u32)NCH : cfg.nch;
+    const u64 M = MM ? ((1ull << (2 * MM)) - 1) : P.m_mask;
+    const u32 nlow = k < 32 ? k : 32, nlow1 = k - 1 < 32 ? k - 1 : 32;  // nts of a k-mer / (k-1)-mer that get_minimizer sees (F2)
+    const u64 r = (u64)blockIdx.x * blockDim.x + tid;
+    u64 q0 = 0, len = 0;
+    u32 emit_from = 0, emit_until = 0xffffffffu, tagval = (u32)r, vslot = 0;
+    bool seq_first = true, seq_last = true, seeded = false;
+    if (r < n_reads) {
+        if (VR) {
+            const VRead v = cc.vreads[r];
+            q0 = v.q0;
+            len = v.len;
+            emit_from = v.emit_from;
+            emit_until = v.emit_until;
+            tagval = vslot = v.slot;
+            seq_first = v.flags & 1u;
+            seq_last = v.flags & 2u;
+            seeded = v.flags & 4u;
+        } else {
+            q0 = starts[r];
+            len = starts[r + 1] - q0;
+            if (cc.long_limit && len >= k && len - k + 1 > cc.long_limit) len = 0;  // a chunked launch takes this one
+        }
+    }
+    const bool live = len >= k;  // counter.cpp:233-235
+    u32 nk = live ? (u32)(len - k + 1) : 0;
+    u32 max_nk = nk;
+    for (int o = 32; o > 0; o >>= 1) {
+        const u32 y = __shfl_xor(max_nk, o, 64);
+        max_nk = y > max_nk ? y : max_nk;
+    }
+    if (max_nk == 0) {  // nothing to scan in this wave; it still takes part in the block's final reservation
+        scan_final_flush(P, packed, out, q_start, q_misc, q_tag, 0, s_wcnt, s_wbase);
+        return;
+    }
+    const u64 KEY0 = order_key_fast<NCH>(0, m, M, nch, s_tabs, s_coef);
+    const u64 KEY0s = read_lane_u64(KEY0, 0);  // the same value, in scalar registers
+
+    // ---- prologue: the low 64 bits of the (k-1)-mer; its last m-mer seeds the rolling candidates
+    u64 cf = 0, cr = 0, low64 = 0;
+    if (live) low64 = load_nts(packed, q0 + (k - 1) - nlow1, nlow1);
+    cf = low64 & M;
+    cr = rc64(cf, m);
+
+    // ---- minimizer of the (k-1)-mer (Kmers.cpp:533): every lane at once, windows in lockstep
+    u64 mini_hash;
+    u32 mini_pos;
+    bool reversed;
+    {
+        const u32 Km = k - 1 - m;
+        u64 best = ~0ull;
+        u32 first = 0, last = 0;
+        bool rf = false, rl = false;
+        for (u32 i = 0; i <= Km; i++) {
+            u64 key;
+            bool rv;
+            if (i < nlow1) {  // inside the low 64 bits; windows that stick out of them are zero-padded (F2)
+                const u64 fwd = (low64 >> (2 * i)) & M;
+                const u64 rcv = rc64(fwd, m);
+                rv = rcv < fwd;
+                key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+            } else {  // beyond the low 64 bits: the all-A m-mer
+                key = KEY0;
+                rv = false;
+            }
+            if (key < best) {
+                best = key;
+                first = last = i;
+                rf = rl = rv;
+            } else if (key == best) {
+                last = i;
+                rl = rv;
+            }
+        }
+        u32 pos;
+        bool rev, need_canon;
+        resolve_ties(first, last, rf, rl, Km, false, false, &pos, &rev, &need_canon);
+        if (need_canon && live) {
+            const u64 hi = k - 1 > 32 ? load_nts(packed, q0, k - 1 - 32) : 0;
+            if (!canonized_as_executed(mk128(low64, hi), k - 1)) rev = false;
+        }
+        mini_hash = best;
+        mini_pos = pos;
+        reversed = rev;
+    }
+    if (seeded) {  // the exact state the previous chunk had before this step
+        const ChunkState st = cc.truth[vslot];
+        mini_hash = st.hash;
+        mini_pos = st.pos_rev & 0x7fffffffu;
+        reversed = st.pos_rev >> 31;
+    }
+    bool foreign = seeded;  // the vector open at a seeded start began before it: it is the previous chunk's
+
+    // ---- the stream of k-mers
+    u32 qcount = 0;  // wave-uniform
+    u32 n = 0, p0 = 0, first_idx = 0, last_idx = 0, n_emitted = 0;
+    bool dead = false;
+    u64 buf = 0;
+    const u32 Km = k - m;
+    for (u32 p = 0; p < max_nk; p++) {
+        const bool act = p < nk && !dead;
+        if (VR && live) {  // the enumerator state before step p, for the chunk-seam check
+            if (p == emit_from && !seq_first && !seeded) cc.spec[vslot] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
+            if (p == emit_until) cc.truth[vslot + 1] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
+        }
+        if ((p & 31) == 0 && p < nk) {
+            const u32 left = (u32)(len - (k - 1 + p));
+            const u32 cnt = left < 32 ? left : 32;
+            buf = load_nts(packed, q0 + k - 1 + p, cnt) << (64 - 2 * cnt);
+        }
+        const u32 c = (u32)(buf >> 62);
+        buf <<= 2;
+        cf = ((cf << 2) + c) & M;
+        cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
+        low64 = (low64 << 2) | c;
+        const bool revf = cr < cf;
+        const u64 h = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
+        mini_pos++;
+        const bool expired = act && mini_pos > w;                  // Kmers.cpp:551
+        const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
+        const bool closed = expired || newmin;
+        // the vector closed by this step (Kmers.cpp:585-588); a close at p == 0 is ignored (:590-592)
+        bool push = closed && p > 0 && !foreign && p0 >= emit_from && p0 < emit_until;  // a chunk emits the vectors that start in its window
+        if (closed) foreign = false;
+        if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) {  // counter.cpp:304-306: returned minimizer == 0
+            push = false;
+            dead = true;
+        }
+        {
+            const unsigned long long bal = __ballot(push);
+            if (push) {
+                const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
+                q_start[at] = q0 + p0;
+                q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17);
+                q_tag[at] = tagval;
+                n_emitted++;
+            }
+            qcount += (u32)__popcll(bal);
+        }
+        // re-scans (get_minimizer on the low 64 bits, Kmers.cpp:367-408): two lanes' k-mers per round, one
+        // window per lane of a half-wave.  Window i of a k-mer is (low64 >> 2i) & M -- zero-padded where it
+        // sticks out of the low 64 bits (F2); windows 32.. of a k > 32 are the all-A m-mer (KEY0), folded in
+        // below without lanes.
+        unsigned long long need = __ballot(expired && !dead);
+        while (need) {
+            const int LA = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const bool two = need != 0;
+            int LB = LA;
+            if (two) {
+                LB = __ffsll((long long)need) - 1;
+                need &= need - 1;
+            }
+            const u64 lowA = read_lane_u64(low64, LA), lowB = read_lane_u64(low64, LB);
+            const u32 wl = lane & 31;
+            const u64 lowL = lane < 32 ? lowA : lowB;
+            const u64 fwd = (lowL >> (2 * wl)) & M;
+            const u64 rcv = rc64(fwd, m);
+            const bool rv = rcv < fwd;
+            u64 key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+            if (wl > Km || wl >= nlow) key = ~0ull;
+            u64 hm = key;  // minimum of this lane's half
+            for (int o = 16; o > 0; o >>= 1) {
+                const u64 y = __shfl_xor(hm, o, 64);
+                hm = y < hm ? y : hm;
+            }
+            const unsigned long long tie = __ballot(key == hm);
+            const unsigned long long rvb = __ballot(rv);
+            for (int half = 0; half < (two ? 2 : 1); half++) {  // wave-uniform, scalar work
+                const int L = half ? LB : LA;
+                const u32 t = (u32)(tie >> (32 * half)), rb = (u32)(rvb >> (32 * half));
+                u64 hmin = read_lane_u64(hm, 32 * half);
+                u32 first = (u32)__ffs((int)t) - 1, last = 31u - (u32)__clz((int)t);
+                bool rf = (rb >> first) & 1, rl = (rb >> last) & 1;
+                if (Km >= 32) {  // windows 32..Km: the all-A m-mer
+                    if (KEY0s < hmin) {
+                        hmin = KEY0s;
+                        first = 32;
+                        last = Km;
+                        rf = rl = false;
+                    } else if (KEY0s == hmin) {
+                        last = Km;
+                        rl = false;
+                    }
+                }
+                u32 pos;
+                bool rev, need_canon;
+                resolve_ties(first, last, rf, rl, Km, false, false, &pos, &rev, &need_canon);
+                if (need_canon) {  // wave-uniform
+                    const u64 lowX = half ? lowB : lowA;
+                    const u64 qL = read_lane_u64(q0, L) + p;
+                    const u64 hi = k > 32 ? load_nts(packed, qL, k - 32) : 0;
+                    const u64 lo = k >= 32 ? lowX : (lowX & ((1ull << (2 * k)) - 1));
+                    if (!canonized_as_executed(mk128(lo, hi), k)) rev = false;
+                }
+                if ((int)lane == L) {
+                    mini_hash = hmin;
+                    mini_pos = pos;
+                    reversed = rev;
+                }
+            }
+        }
+        if (newmin) {  // Kmers.cpp:572-576
+            mini_hash = h;
+            mini_pos = 0;
+            reversed = revf;
+        }
+        if (act) {
+            const u32 idx = reversed ? w - mini_pos : mini_pos;  // Kmers.cpp:578-584
+            if (closed && (p > 0 || seeded)) n = 0;  // a close at a seeded start is a real one: a new vector begins here
+            if (n == 0) {
+                p0 = p;
+                first_idx = idx;
+            }
+            last_idx = idx;
+            n++;
+        }
+        // turn queued super-k-mers into records with full waves.  All waves append to one record counter, and
+        // same-address atomics serialise device-wide (~15 ns each): one reservation per flush, not per record
+        if (qcount + 64 > cfg.qcap) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)qcount);
+            base = read_lane_u64(base, 0);
+            for (u32 e = lane; e < qcount; e += 64) {
+                const u32 mi = q_misc[e];
+                emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], q_start[e] | ((u64)((mi >> 17) & 1) << 63), base + e);
+            }
+            qcount = 0;
+        }
+    }
+    // the last vector of every read (Kmers.cpp:596-601)
+    {
+        // the sequence's true end closes the open vector; it belongs to the chunk in whose window it started
+        bool push = live && !dead && n > 0 && seq_last && !foreign && p0 >= emit_from && p0 < emit_until;
+        if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) push = false;
+        const unsigned long long bal = __ballot(push);
+        if (push) {
+            const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
+            q_start[at] = q0 + p0;
+            q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17);
+            q_tag[at] = tagval;
+        }
+        qcount += (u32)__popcll(bal);
+    }
+    scan_final_flush(P, packed, out, q_start, q_misc, q_tag, qcount, s_wcnt, s_wbase);
+}

@@ -18,7 +18,7 @@ import torch.distributed as dist
 def owner_of_bucket(bucket, b: int, part_bits: int, n_owners: int):
     """Owner rank of a bucket id: partitions (contiguous bucket ranges) are dealt in
     contiguous blocks, owner = partition * N >> part_bits.  Mirrors k_owner_hist /
-    k_scatter in csrc/brisk_kernels.hip; works on ints and numpy arrays."""
+    k_scatter in csrc/brisk_partition.hip; works on ints and numpy arrays."""
     shift = 2 * b - part_bits
     part = bucket >> shift
     return (part * n_owners) >> part_bits

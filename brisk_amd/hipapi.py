@@ -33,7 +33,8 @@ def library_path() -> str:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). In-tree output."""
     out = library_path()
-    srcs = [os.path.join(HERE, "csrc", f) for f in ("brisk_capi.hip", "brisk_kernels.hip", "brisk_device.h")]
+    srcs = [os.path.join(HERE, "csrc", f) for f in ("brisk_capi.hip", "brisk_kernels.hip", "brisk_scan.hip", "brisk_partition.hip", "brisk_insert.hip",
+                                                    "brisk_readout.hip", "brisk_device.h")]
     srcs.append(os.path.join(ROOT, "include", "brisk_hip.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out

@@ -602,7 +602,7 @@ def test_batch_splits_when_the_arena_reserve_does_not_fit(B, O, monkeypatch):
     want = O.count(reads, k, m, b)
     inst = sum(len(r) - k + 1 for r in reads)
     monkeypatch.delenv("BRISK_NO_VMM", raising=False)  # this test sets it itself, further down
-    slack = 4096 * 16384  # INSERT_SLOTS x ARENA_CHUNK of brisk_kernels.hip: one partly used private chunk per persistent wave
+    slack = 4096 * 16384  # INSERT_SLOTS x ARENA_CHUNK of csrc/brisk_insert.hip: one partly used private chunk per persistent wave
     monkeypatch.setenv("BRISK_ARENA_LIMIT", str(slack + inst // 2))  # the slack plus half the pessimistic bound
     assert gpu_count(B, reads, k, m, b) == want
     monkeypatch.setenv("BRISK_ARENA_LIMIT", "1000")  # nothing fits: a clean error, not a crash
