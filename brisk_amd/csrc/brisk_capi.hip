@@ -753,7 +753,7 @@ int g_upload_device = -1;
 
 int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, u64 n_words) {
     const u64 n_chunks = (nb + kUploadChunk - 1) / kUploadChunk;
-    if (n_chunks < 4) {  // small input: not worth the threads
+    auto in_one_piece = [&]() -> int {  // plain copy of the whole input, then one pack launch
         int rc;
         if ((rc = ensure(h, h->bases_tmp, nb + 16))) return rc;
         if (nb) HIPCHK(h, hipMemcpyAsync(h->bases_tmp.p, src, nb, hipMemcpyHostToDevice, h->stream));
@@ -762,7 +762,8 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
             hipLaunchKernelGGL(k_pack_ascii, dim3(nblocks(n_words, 256)), dim3(256), 0, h->stream, (const uint8_t*)h->bases_tmp.p, nb, d_packed, n_words);
         }
         return launch_check(h, "k_pack_ascii");
-    }
+    };
+    if (n_chunks < 4) return in_one_piece();  // small input: not worth the threads
     std::lock_guard<std::mutex> lk(g_upload_mu);
     if (g_upload_device != h->device) {  // first use on this device: the lanes stay for the life of the process
         for (UploadLane& l : g_upload)
@@ -774,13 +775,17 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
         for (UploadLane& l : g_upload)
             if (l.st) hipStreamDestroy(l.st);
         g_upload.assign(kUploadLanes, UploadLane{});
+        g_upload_device = -1;
+        bool ok = true;
         for (UploadLane& l : g_upload) {
-            HIPCHK(h, hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
-            for (int i = 0; i < 2; i++) {
-                HIPCHK(h, hipHostMalloc((void**)&l.pin[i], kUploadChunk));
-                HIPCHK(h, hipMalloc((void**)&l.dev[i], kUploadChunk));
-                HIPCHK(h, hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming));
-            }
+            ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 2 && ok; i++)
+                ok = hipHostMalloc((void**)&l.pin[i], kUploadChunk) == hipSuccess && hipMalloc((void**)&l.dev[i], kUploadChunk) == hipSuccess &&
+                     hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) {  // no room for the pinned lanes (192 MiB of host, as much of device memory): the plain path still works
+            (void)hipGetLastError();
+            return in_one_piece();
         }
         g_upload_device = h->device;
     }
