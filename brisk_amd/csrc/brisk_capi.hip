@@ -1159,6 +1159,7 @@ BRISK_API int brisk_hip_insert_reads(brisk_hip_index* h, const char* bases, cons
 
 BRISK_API int brisk_hip_get_reads(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t* per_read_sum) {
     if (!h || (n_reads && (!bases || !offsets || !per_read_sum))) return BRISK_HIP_EINVAL;
+    if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "get_reads on a sharded index sees one bucket range only: use scan_query / route_tagged / query_records");
     HIPCHK(h, hipSetDevice(h->device));
     return for_each_host_batch(h, bases, offsets, n_reads, [&](u64 r0, u64 nr) -> int {
         int rc;
@@ -1174,6 +1175,7 @@ BRISK_API int brisk_hip_get_reads(brisk_hip_index* h, const char* bases, const u
 BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, const uint64_t* kmer_hi, const uint8_t* minimizer_idx, uint64_t n,
                                uint8_t* out_data, uint8_t* out_found) {
     if (!h || (n && (!kmer_lo || !kmer_hi || !minimizer_idx || !out_data || !out_found))) return BRISK_HIP_EINVAL;
+    if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "lookup on a sharded index sees one bucket range only: use scan_query / route_tagged / query_records");
     if (n == 0) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
@@ -1330,7 +1332,14 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     if (!h || !n_records || (n_reads && (!d_packed || !d_starts)) || (cap_records && !d_records)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     *n_records = 0;
-    if (!n_reads) return BRISK_HIP_OK;
+    if (!n_reads) {  // an empty piece of a sharded job still exports a (zero) histogram: the exchange is collective
+        h->scan_hist_valid = false;
+        if (h->P.n_owners > 1) {
+            HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+            h->scan_hist_valid = true;
+        }
+        return BRISK_HIP_OK;
+    }
     u64 n = 0;
     u64 bound = 0;
     int rc = count_kmers(h, d_starts, n_reads, &bound);

@@ -15,12 +15,15 @@ import torch
 import torch.distributed as dist
 
 
-def owner_of_bucket(bucket, b: int, part_bits: int, n_owners: int):
-    """Owner rank of a bucket id: partitions (contiguous bucket ranges) are dealt in
-    contiguous blocks, owner = partition * N >> part_bits.  Mirrors k_owner_hist /
-    k_scatter in csrc/brisk_partition.hip; works on ints and numpy arrays."""
-    shift = 2 * b - part_bits
-    part = bucket >> shift
+def owner_of_bucket(rid, b: int, part_bits: int, n_owners: int, ext_bits: int = 0):
+    """Owner rank of a routing id (the bucket id followed by the layout's `ext_bits` extra minimizer-hash bits; the
+    bucket id itself when ext_bits == 0): partitions are dealt in contiguous blocks, owner = partition * N >> part_bits
+    with partition = rid >> (2b + ext_bits - part_bits).  Mirrors owner_of_record in csrc/brisk_partition.hip; works on
+    ints and numpy arrays.  part_bits and ext_bits come from BriskHip.layout."""
+    shift = 2 * b + ext_bits - part_bits
+    if shift < 0:
+        raise ValueError("part_bits exceeds the routing id's 2b + ext_bits bits")
+    part = rid >> shift
     return (part * n_owners) >> part_bits
 
 
@@ -94,6 +97,17 @@ def return_sums(sums: torch.Tensor, recv_counts, send_counts, tags: torch.Tensor
     return per_read
 
 
+def agree_pieces(n_reads: int, device, group=None, four_from: int = 1 << 22) -> int:
+    """The piece count of one ShardedCounter.count_packed call, the same on every rank: every piece issues the same
+    all-to-alls on every rank, so the count follows the LARGEST share (one all-reduce(MAX)), not the local one.
+    Only the last piece's all-to-all is exposed: four pieces for a large batch, two for a small one."""
+    gloo = dist.get_backend(group) == "gloo"
+    most = torch.tensor([int(n_reads)], dtype=torch.int64, device=torch.device("cpu") if gloo else device)
+    dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
+    most = int(most.item())
+    return 4 if most >= four_from else (2 if most >= 2 else 1)
+
+
 class ShardedCounter:
     """A rank's share of a k-mer counting job: owns the buckets of its partition range."""
 
@@ -108,16 +122,25 @@ class ShardedCounter:
         self._rec = self._out = self._inbox = self._hist = None
         self._cap = 0
 
-    def count_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int) -> None:
+    # reads per rank from which a batch goes in four pieces (patchable: the tests lower it)
+    PIECES4_MIN_READS = 1 << 22
+
+    def count_packed(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int, pieces: Optional[int] = None) -> None:
         """Count this rank's reads into the sharded index.  The reads go in pieces (four for a large batch) so that the
         all-to-all of one piece's records runs while the next piece is scanned; the owner inserts everything it received
-        at once."""
+        at once.
+
+        COLLECTIVE: every rank of the group must call this the same number of times.  Ranks may hold different
+        numbers of reads (0 included: the last batch of a sharded FASTA): the piece count -- every piece issues the
+        same three all-to-alls on every rank -- is agreed on with one all-reduce(MAX) of n_reads, or given
+        explicitly (the same value on every rank) as `pieces`; a rank with fewer reads than pieces runs empty pieces."""
         ix, W = self.ix, self.W
         if self.world == 1:
             ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
             return
         import brisk_amd
-        pieces = 4 if n_reads >= (1 << 22) else (2 if n_reads >= 2 else 1)  # only the last piece's all-to-all is exposed
+        if pieces is None:
+            pieces = agree_pieces(n_reads, self.dev, self.group, self.PIECES4_MIN_READS)
         cuts = [n_reads * i // pieces for i in range(pieces + 1)]
         halves = list(zip(cuts[:-1], cuts[1:]))
         n_parts = 1 << ix.layout["part_bits"]
@@ -128,7 +151,7 @@ class ShardedCounter:
                 self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
                 self._out = [torch.empty(cap * W, dtype=torch.int64, device=self.dev) for _ in halves]
                 self._inbox = torch.empty(len(halves) * (cap + cap // 4) * W, dtype=torch.int64, device=self.dev)
-            if self._hist is None:
+            if self._hist is None or len(self._hist) != len(halves):
                 self._hist = [torch.empty(n_parts, dtype=torch.int64, device=self.dev) for _ in halves]
             slices = None
             works, n_in_total, n_slices = [], 0, 0

@@ -49,8 +49,8 @@ class Brisk {
     std::vector<DATA*> insert_superkmer(std::vector<kmer_full>& superkmer, std::vector<bool>& newly_inserted) {
         std::vector<DATA*> result;
         if (superkmer.empty()) return result;
+        std::lock_guard<std::mutex> g(call_mu_);  // before flatten(): lo_/hi_/idx_ are shared by every caller of this index
         flatten(superkmer);
-        std::lock_guard<std::mutex> g(call_mu_);
         ids_.resize(superkmer.size());
         new_.resize(superkmer.size());
         check(brisk_hip_upsert_kmers(menu->handle, lo_.data(), hi_.data(), idx_.data(), superkmer.size(), ids_.data(), new_.data()));

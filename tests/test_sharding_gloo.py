@@ -164,3 +164,42 @@ def test_two_rank_get_return_trip_matches_oracle(O, k, m, b, part_bits):
     O.index_free(h)
     for r in range(world):
         assert res[r] == want[r::world]
+
+
+def _pieces_worker(rank, world, port, shares, four_from, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brisk_amd.exchange import agree_pieces
+    got = [agree_pieces(n[rank], torch.device("cpu"), None, four_from) for n in shares]
+    q.put((rank, got))
+    dist.destroy_process_group()
+
+
+def test_piece_count_is_collective_with_unequal_shares():
+    """the number of pieces (and with it the number of all-to-alls) of a sharded batch must not depend on a
+    rank's own share: ranks on different sides of the thresholds, or with no reads at all, agree on one count."""
+    world = 2
+    shares = [(0, 0), (1, 0), (0, 5), (3, 99), (100, 7), (100, 0), (99, 99)]  # (rank 0, rank 1) reads per call
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pieces_worker, args=(r, world, port, shares, 100, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == [1, 1, 2, 2, 4, 4, 2]
+
+
+def test_owner_of_bucket_takes_the_routing_id():
+    from brisk_amd.exchange import owner_of_bucket
+    # b = 4 with the default layout: 8 bucket bits + 16 ext bits = 24 routing bits = part_bits; owner = top of the routing id
+    rid = np.array([0, (1 << 23) - 1, 1 << 23, (1 << 24) - 1], dtype=np.int64)
+    assert owner_of_bucket(rid, 4, 24, 2, ext_bits=16).tolist() == [0, 0, 1, 1]
+    assert owner_of_bucket(rid >> 16, 4, 8, 2).tolist() == [0, 0, 1, 1]  # explicit part_bits: plain bucket ranges
+    with pytest.raises(ValueError):
+        owner_of_bucket(rid, 4, 24, 2)
