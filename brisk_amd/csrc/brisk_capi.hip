@@ -421,13 +421,26 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         // partitions of many records (few distinct minimizers: m <= 11) take the 512-instance kernel: half as many chunks, and
         // with them half as many passes over a partition's entries, outweigh its 2 waves per SIMD (k31/m11/b11: 48 -> 36 ms)
         const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
-        if (n_rec / n_touched > 64)
-            hipLaunchKernelGGL(k_insert_big, dim3(std::min<u32>(batches, INSERT_SLOTS / 2)), dim3(64), 0, h->stream, P, (u64*)h->parted.p,
-                               (const PartDesc*)h->desc.p, n_touched, h->ix, (u32*)(h->d_small + 6));
-        else
-            hipLaunchKernelGGL(k_insert, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (u64*)h->parted.p,
-                               (const PartDesc*)h->desc.p, n_touched, h->ix, (u32*)(h->d_small + 6));
-        if ((rc = launch_check(h, n_rec / n_touched > 64 ? "k_insert_big" : "k_insert"))) return rc;
+        const bool big = n_rec / n_touched > 64;
+        const dim3 grid(std::min<u32>(batches, big ? INSERT_SLOTS / 2 : INSERT_SLOTS));
+        // instantiations with the record geometry (nw, k - b, routing-id bits kept in the key) as constants, for the
+        // common parameter sets under the default partition layout; anything else takes the generic body
+#define LAUNCH_INSERT(NW, KB, SH)                                                                                                                              \
+    {                                                                                                                                                          \
+        if (big)                                                                                                                                               \
+            hipLaunchKernelGGL((k_insert_big<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, (u64*)h->parted.p, (const PartDesc*)h->desc.p, n_touched, h->ix, \
+                               (u32*)(h->d_small + 6));                                                                                                        \
+        else                                                                                                                                                   \
+            hipLaunchKernelGGL((k_insert<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, (u64*)h->parted.p, (const PartDesc*)h->desc.p, n_touched, h->ix,     \
+                               (u32*)(h->d_small + 6));                                                                                                        \
+    }
+        static const bool generic_only = getenv("BRISK_INSERT_GENERIC") != nullptr;  // A/B and tests: force the run-time body
+        if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_INSERT(3, 49, 4)        // k63 m21 b14
+        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_INSERT(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_INSERT(2, 20, 0)  // k31 m11 b11
+        else LAUNCH_INSERT(0, 0, 0)
+#undef LAUNCH_INSERT
+        if ((rc = launch_check(h, big ? "k_insert_big" : "k_insert"))) return rc;
     }
     h->nb_skmers += n_rec;
     h->dir_snapshot_valid = false;
@@ -1036,6 +1049,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMalloc((void**)&h->d_touched, np * 4));
         h->n_scan_blocks = nblocks(np, 256 * SCAN_ITEMS);
         HIPCHK(h, hipMalloc((void**)&h->d_block_sums, (size_t)(h->n_scan_blocks + 1) * 4));
+        h->ix.bits_check = 2u * b < 20u ? 1u : 0u;
         HIPCHK(h, hipMalloc((void**)&h->ix.err, 8));
         HIPCHK(h, hipMemsetAsync(h->ix.err, 0, 8, h->stream));
         HIPCHK(h, hipMalloc((void**)&h->d_id_counter, 8));
@@ -1653,6 +1667,19 @@ BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mme
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return BRISK_HIP_OK;
 }
+
+#ifdef BRISK_PHASE_PROF
+BRISK_API int brisk_hip_debug_phases(uint64_t out[32], int reset) {  // debug builds only (tools/phase_profile.py)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * 8) != hipSuccess) return BRISK_HIP_EHIP;
+    if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_cnt), 16 * 8) != hipSuccess) return BRISK_HIP_EHIP;
+    if (reset) {
+        uint64_t z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, 16 * 8) != hipSuccess) return BRISK_HIP_EHIP;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_cnt), z, 16 * 8) != hipSuccess) return BRISK_HIP_EHIP;
+    }
+    return BRISK_HIP_OK;
+}
+#endif
 
 // ---- measurement ---------------------------------------------------------------
 BRISK_API int brisk_hip_profile_enable(brisk_hip_index* h, int on) {

@@ -29,6 +29,22 @@
 #ifndef WI_WAVES_PER_EU
 #define WI_WAVES_PER_EU 4
 #endif
+// Phase timers of k_insert (debug builds only: -DBRISK_PHASE_PROF): s_memtime at phase boundaries, scalar arithmetic,
+// one atomic per phase and wave at the end.  Wall cycles of a wave, so they include what it waits for.
+#ifdef BRISK_PHASE_PROF
+__device__ unsigned long long g_phase[16];
+#define PHASE_DECL unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last = __builtin_amdgcn_s_memtime(); u32 dbg_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PHASE(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_last; ph_last = t_; }  /* phase i ends here */
+__device__ unsigned long long g_cnt[16];
+#define PHASE_FLUSH { PHASE(10) if (threadIdx.x == 0) { _Pragma("unroll") for (int q_ = 0; q_ < 12; q_++) atomicAdd(&g_phase[q_], ph_acc[q_]); \
+                                                         _Pragma("unroll") for (int q_ = 0; q_ < 12; q_++) atomicAdd(&g_cnt[q_], (unsigned long long)dbg_cnt[q_]); } }
+#define CNT(i, v) dbg_cnt[i] += (v);
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_FLUSH
+#define CNT(i, v)
+#endif
 struct IndexDev {
     u64* keys;                   // 2 u64 per entry
     uint8_t* counts;
@@ -41,6 +57,7 @@ struct IndexDev {
     u32* ids;                    // entry-id mode only: stable dense id of every entry (insertion order)
     unsigned long long arena_cap;  // entries the arena can hold
     u32* err;                    // sticky violation bits: 1 scatter slot out of range, 2 arena exhausted, 4 chunk overflow
+    u32 bits_check;              // few buckets (2b < 20): read a bucket-bitmap word before or-ing into it
 };
 
 // k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
@@ -99,6 +116,17 @@ __device__ __forceinline__ u32 wave_incl_max_scan(u32 x) {
     WAVE_SCAN_STEP(x, op_max_u32, 0x142, 0xa)
     WAVE_SCAN_STEP(x, op_max_u32, 0x143, 0xc)
     return x;
+}
+// OR over all 64 lanes, the same value in every lane (through lane 63 and a scalar register).  Full EXEC mask only.
+__device__ __forceinline__ u32 op_or_u32(u32 a, u32 b) { return a | b; }
+__device__ __forceinline__ u32 wave_or_all(u32 x) {
+    WAVE_SCAN_STEP(x, op_or_u32, 0x111, 0xf)
+    WAVE_SCAN_STEP(x, op_or_u32, 0x112, 0xf)
+    WAVE_SCAN_STEP(x, op_or_u32, 0x114, 0xf)
+    WAVE_SCAN_STEP(x, op_or_u32, 0x118, 0xf)
+    WAVE_SCAN_STEP(x, op_or_u32, 0x142, 0xa)
+    WAVE_SCAN_STEP(x, op_or_u32, 0x143, 0xc)
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
 }
 // value of the previous lane (0 for lane 0)
 __device__ __forceinline__ u32 wave_prev_lane(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }  // wave_shr:1
@@ -188,6 +216,115 @@ __device__ __forceinline__ void expand_and_dedupe(const BriskParams& P, u32 lane
     }
 }
 
+// ---- compile-time record geometry (the common parameter sets): records are laid down in LDS as 32-bit words of
+// (C << 6) followed by one packed info word, and k-mer j's 128-bit entry key is five adjacent words funnel-shifted
+// (v_alignbit) by s = 2(n-1-j): bits [0,6) of the window then take idx', bits above 2kb+6 the routing id's low bits.
+// 36 vector instructions per instance instead of 73 with the u64 shifts of record_kmer_lds + make_key + shl128.
+template <u32 NW>
+struct RecGeom {
+    static constexpr u32 CW = 2 * NW + 1;     // words of C << 6
+    static constexpr u32 RS = 2 * NW + 3;     // record stride in words (odd: lanes on different records hit different banks)
+    static constexpr u32 INFO = 2 * NW + 1;   // [pref:10 | n:8 | idx0:8 | routing id low bits:6]
+};
+template <u32 NW>
+__device__ __forceinline__ void store_rec_words(u32* dst, const RecRegs& rr, u32 info) {
+    const u64 c0 = rr.w0, c1 = NW > 1 ? rr.w1 : 0, c2 = NW > 2 ? rr.w2 : 0, c3 = NW > 3 ? rr.w3 : 0;
+    const u64 s0 = c0 << 6, s1 = (c1 << 6) | (c0 >> 58), s2 = (c2 << 6) | (c1 >> 58), s3 = (c3 << 6) | (c2 >> 58);
+    const u32 top = (u32)((NW == 1 ? c0 : NW == 2 ? c1 : NW == 3 ? c2 : c3) >> 58);
+    dst[0] = (u32)s0;
+    dst[1] = (u32)(s0 >> 32);
+    if (NW > 1) { dst[2] = (u32)s1; dst[3] = (u32)(s1 >> 32); }
+    if (NW > 2) { dst[4] = (u32)s2; dst[5] = (u32)(s2 >> 32); }
+    if (NW > 3) { dst[6] = (u32)s3; dst[7] = (u32)(s3 >> 32); }
+    dst[2 * NW] = top;
+    dst[RecGeom<NW>::INFO] = info;
+    dst[RecGeom<NW>::INFO + 1] = 0;  // read (and shifted out) by the last k-mer's window
+}
+template <u32 NI, u32 NW, u32 KB, u32 SHIFT>
+__device__ __forceinline__ void expand_and_dedupe_words(u32 lane, u32 ninst, u32 tsize, const u32* s_rw, const uint8_t* s_irec, const u32* s_rmult,
+                                                        u64* s_key, u32* s_tab, u32* dbg_rounds) {
+    constexpr u32 RS = RecGeom<NW>::RS, INFO = RecGeom<NW>::INFO, KBITS = 2 * KB + 6;
+    static_assert(KBITS + SHIFT <= 128 && SHIFT <= 6, "entry key: [routing id low bits | compacted k-mer | idx']");
+    u64 klo[NI], khi[NI];
+    u32 hh[NI], mult[NI];
+    u32 rix[NI];
+#pragma unroll
+    for (u32 it = 0; it < NI; it++) {
+        const u32 i = it * 64 + lane;
+        rix[it] = s_irec[i < ninst ? i : 0];
+    }
+#pragma unroll
+    for (u32 it = 0; it < NI; it++) {
+        const u32 i = it * 64 + lane;
+        const u32* base = s_rw + rix[it] * RS;
+        const u32 info = base[INFO];
+        const u32 j = i < ninst ? i - (info & 0x3ffu) : 0;
+        const u32 n = (info >> 10) & 0xffu;
+        const u32 s = 2 * (n - 1 - j);
+        const u32* wp = base + (s >> 5);
+        const u32 sh = s & 31;
+        const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
+        u32 k0 = __builtin_amdgcn_alignbit(w1, w0, sh), k1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+        u32 k2 = __builtin_amdgcn_alignbit(w3, w2, sh), k3 = __builtin_amdgcn_alignbit(w4, w3, sh);
+        k0 = (k0 & ~0x3fu) | (((info >> 18) & 0xffu) + j);  // idx' = idx0' + j (SuperKmerLight.hpp:98)
+        // keep the 2kb + 6 key bits, put the routing id's low bits on top
+        constexpr u32 m0 = KBITS >= 32 ? ~0u : (1u << KBITS) - 1, m1 = KBITS >= 64 ? ~0u : KBITS <= 32 ? 0u : (1u << (KBITS - 32)) - 1;
+        constexpr u32 m2 = KBITS >= 96 ? ~0u : KBITS <= 64 ? 0u : (1u << (KBITS - 64)) - 1, m3 = KBITS >= 128 ? ~0u : KBITS <= 96 ? 0u : (1u << (KBITS - 96)) - 1;
+        k0 &= m0; k1 &= m1; k2 &= m2; k3 &= m3;
+        u64 lo = ((u64)k1 << 32) | k0, hi = ((u64)k3 << 32) | k2;
+        if (SHIFT) {
+            const u64 rl = (info >> 26) & ((1u << SHIFT) - 1);
+            if (KBITS >= 64) hi |= rl << (KBITS - 64);
+            else {
+                lo |= rl << KBITS;
+                if (KBITS + SHIFT > 64) hi |= rl >> (64 - KBITS);
+            }
+        }
+        klo[it] = lo;
+        khi[it] = hi;
+        hh[it] = hash_key32(mk128(lo, hi)) & (tsize - 1);
+        mult[it] = (s_rmult[rix[it]] & 0xffu) << WI_CNT_SHIFT;  // counts wrap at 256: so may the multiplicities
+        if (i < ninst) {
+            s_key[2 * i] = lo;
+            s_key[2 * i + 1] = hi;
+        }
+    }
+    wave_sync();
+    u32 pending = 0;
+#pragma unroll
+    for (u32 it = 0; it < NI; it++)
+        if (it * 64 + lane < ninst) pending |= 1u << it;
+    while (__any(pending != 0)) {
+        *dbg_rounds += NI;
+        u32 old[NI];
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            old[it] = EMPTY_SLOT;
+            if (pending >> it & 1) old[it] = atomicCAS(&s_tab[hh[it]], EMPTY_SLOT, (it * 64 + lane) | mult[it]);
+        }
+        u64 olo[NI], ohi[NI];
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            const u32 oi = old[it] == EMPTY_SLOT ? 0 : (old[it] & WI_IDX_MASK);
+            olo[it] = s_key[2 * oi];
+            ohi[it] = s_key[2 * oi + 1];
+        }
+#pragma unroll
+        for (u32 it = 0; it < NI; it++) {
+            if (pending >> it & 1) {
+                if (old[it] == EMPTY_SLOT) {
+                    pending &= ~(1u << it);
+                } else if (olo[it] == klo[it] && ohi[it] == khi[it]) {
+                    atomicAdd(&s_tab[hh[it]], mult[it]);
+                    pending &= ~(1u << it);
+                } else {
+                    hh[it] = (hh[it] + 1) & (tsize - 1);
+                }
+            }
+        }
+    }
+}
+
 // Record-level de-duplication of the <= 64 records the lanes hold (also in s_rec): the first copy of every distinct record
 // survives, s_rmult[its lane] = the multiplicities of all its copies added up; returns whether this lane's record is a
 // later copy.  Header bits 48..55 carry a record's multiplicity (mod 256: counts wrap there anyway) once a partition's
@@ -228,22 +365,39 @@ __device__ __forceinline__ bool dedupe_records(u32 stride, const RecRegs& rr, u3
 // MAXI: k-mer instances per chunk.  256 (10 KB of LDS, 128 registers: 4 waves per SIMD) for the usual partitions of a
 // few hundred instances; 512 (2 waves per SIMD) when partitions are big -- few distinct minimizers, as with m <= 11 --
 // and the passes over a partition's entries saved by half as many chunks outweigh the occupancy.
-template <u32 MAXI>
-__device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
+// NW > 0: the record width (u64 words of the compacted super-k-mer), kb = k - b and the routing-id bits kept in the
+// key are compile-time constants (the common parameter sets; the host picks the instantiation): shifts, masks and
+// strides fold, nothing of BriskParams stays in scalar registers (the generic body spills 48 of them into vector
+// lanes and pays a v_readlane per use), and k-mers are cut out of 32-bit words (expand_and_dedupe_words).  NW == 0:
+// everything from P at run time.
+template <u32 MAXI, u32 NW, u32 KB, u32 SHIFT>
+__device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
                                             u32* __restrict__ work_counter) {
+    BriskParams P = PP;
+    if (NW) {  // the fields the body reads, as constants
+        P.nw = NW;
+        P.stride = NW + 1;
+        P.kb = KB;
+        P.shift = SHIFT;
+    }
     constexpr u32 TABLE = 2 * MAXI, TS = TABLE / 64, NI = MAXI / 64;
     static_assert(MAXI % 256 == 0 && MAXI <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
     __shared__ u64 s_key[2 * MAXI];
-    __shared__ u64 s_rec[WI_MAX_REC * 5 > MAXI / 2 ? WI_MAX_REC * 5 : MAXI / 2];
+    // records as u64 words (record-level de-duplication), then -- NW > 0 -- again as shifted 32-bit words (+4: the last
+    // record's window reads up to two words past its slot), then the list of new entries
+    constexpr u32 REC_U64 = WI_MAX_REC * 5 > MAXI / 2 ? WI_MAX_REC * 5 : MAXI / 2;
+    __shared__ u64 s_rec[REC_U64];
+    static_assert(NW == 0 || (WI_MAX_REC * RecGeom<NW ? NW : 1>::RS + 4) * 4 <= REC_U64 * 8, "shifted record words must fit the record buffer");
+    u32* s_rw = (u32*)s_rec;
     __shared__ u32 s_tab[TABLE];
     __shared__ u32 s_pref[WI_MAX_REC + 1];
     u32* s_list = (u32*)s_rec;  // [MAXI] the new entries' table words: built after the records have been expanded
     __shared__ u32 s_rtab[2 * WI_MAX_REC];
     __shared__ u32 s_rmult[WI_MAX_REC];
     __shared__ __attribute__((aligned(4))) uint8_t s_irec[MAXI];
-    __shared__ u32 s_bm[2];
 
     const u32 lane = threadIdx.x;
+    PHASE_DECL
     unsigned long long acur = ix.slot_cur[blockIdx.x], aend = ix.slot_end[blockIdx.x], garbage = 0;
     const u32 kbits = 2 * P.kb + 6;
 
@@ -264,6 +418,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
             if (tn < t_end) dn = desc[tn];
             RecRegs rn{0, 0, 0, 0, 0};
 
+            CNT(0, 1)
             const u32 part = d.part;
             u32 r_end = d.r_begin + d.n_rec;
             u32 n_exist = d.n_exist;
@@ -314,6 +469,8 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
 
             for (u32 rc = d.r_begin; rc < r_end;) {
                 // ---- pick the chunk: up to WI_MAX_REC records / MAXI instances
+                PHASE(0)
+                CNT(1, 1)
                 const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
                 if (rc != d.r_begin) rr = load_rec_regs(P, rec, rc, avail, lane);
                 wave_sync();
@@ -337,6 +494,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                 const u32 rawfit = (u32)__popcll(__ballot(lane < avail && x0 <= MAXI));  // >= 1; a prefix: x0 is monotone
                 u32 nrec = avail, my_n = 0, x = 0, ninst = 0;
                 for (int attempt = 0;; attempt++) {
+                    CNT(2, 1)
                     const bool dup = dedupe_records(P.stride, rr, my_mult, nrec, lane, s_rec, s_rtab, s_rmult);
                     my_n = (lane < nrec && !dup) ? raw_n : 0;
                     x = wave_incl_scan(my_n, lane);
@@ -346,6 +504,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                     nrec = (attempt >= 2 || fit <= rawfit) ? rawfit : min(fit, nrec - 1);
                     wave_sync();
                 }
+                PHASE(1)
                 const u32 raw_inst = __shfl(x0, nrec - 1, 64);
                 u32 tsize = 128;
                 while (tsize < 2 * ninst && tsize < TABLE) tsize <<= 1;
@@ -384,18 +543,32 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                 if (rc == d.r_begin && tn < t_end) rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
 
                 // ---- 0/1. expand to entry keys and de-duplicate
-                if (P.nw == 3) {  // k63/m21/b14 and neighbours: compile-time record width
-                    if (ninst <= 64) expand_and_dedupe<1, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else if (ninst <= 128) expand_and_dedupe<2, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else if (ninst <= 192) expand_and_dedupe<3, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
-                    else expand_and_dedupe<NI, 3>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
+                PHASE(2)
+                u32 dbg_r = 0;
+                CNT(3, (ninst + 63) / 64)
+                CNT(4, ninst)
+                CNT(5, nrec)
+                if (NW) {
+                    // the records once more, as 32-bit words of C << 6 with their packed info (the u64 copy was for the
+                    // record-level pass above; its last reader is behind the wave_sync before the instance map)
+                    if (lane < nrec) {
+                        const u32 info = (x - my_n) | (raw_n << 10) | (hdr_idx0(my_hdr) << 18) | ((hdr_bucket(my_hdr) & ((1u << SHIFT) - 1)) << 26);
+                        store_rec_words<NW ? NW : 1>(s_rw + lane * RecGeom<NW ? NW : 1>::RS, rr, info);
+                    }
+                    wave_sync();
+                    if (ninst <= 64) expand_and_dedupe_words<1, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
+                    else if (ninst <= 128) expand_and_dedupe_words<2, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
+                    else if (ninst <= 192) expand_and_dedupe_words<3, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
+                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe_words<4, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
+                    else expand_and_dedupe_words<NI, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
                 } else {
                     if (ninst <= 128) expand_and_dedupe<2, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else expand_and_dedupe<NI, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                 }
                 wave_sync();
+                CNT(8, dbg_r)
+                PHASE(3)
 
                 // ---- 2. existing entries probe the table.  After the first chunk they include what this wave
                 // appended itself: same wave, same CU, so those stores only have to be complete (workgroup
@@ -436,6 +609,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                 }
                 wave_sync();
 
+                PHASE(5)
                 // ---- 3. append the unmatched ones: compact them in LDS, then write them out with
                 // full waves (a store instruction costs the same with 3 active lanes as with 64)
                 u32 n_new = 0;
@@ -450,6 +624,9 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                     }
                 }
                 wave_sync();
+                PHASE(6)
+                CNT(6, (n_new + 63) / 64)
+                CNT(7, n_new)
                 inst_left -= raw_inst;
                 if (n_exist + n_new > cap) {
                     // move to a fresh slice, sized so that this partition moves at most once per batch
@@ -485,6 +662,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                     }
                     off = noff;
                 }
+                PHASE(7)
                 for (u32 q = lane; q < n_new; q += 64) {
                     const u32 v = s_list[q];
                     const u32 i = v & WI_IDX_MASK;
@@ -500,16 +678,13 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                 }
                 n_exist += n_new;
                 rc += nrec;
+                PHASE(8)
 
             }
-            if (P.shift <= 6) {  // OR the lanes' bucket bits together through LDS
-                if (lane < 2) s_bm[lane] = 0;
-                wave_sync();
-                if (bm0) atomicOr(&s_bm[0], bm0);
-                if (bm1) atomicOr(&s_bm[1], bm1);
-                wave_sync();
-                bm0 = s_bm[0];
-                bm1 = s_bm[1];
+            if (P.shift <= 6) {  // OR the lanes' bucket bits together on the DPP network (an LDS atomicOr on one word is turned
+                                 // by the compiler into a scalar loop over the active lanes: 64 rounds per partition)
+                bm0 = wave_or_all(bm0);
+                if (P.shift == 6) bm1 = wave_or_all(bm1);
             }
             if (lane == 0) ix.dir[part] = DirEnt{off, n_exist, cap};
             // bucket occupancy bits: exact when a partition holds <= 64 buckets (shift <= 6);
@@ -518,21 +693,25 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
                 const u32 mask = lane == 0 ? bm0 : bm1;
                 const u32 nb = 1u << P.shift;  // buckets per partition
                 const u64 first = ((u64)part << P.shift) >> P.ext_bits;  // ext_bits > 0 => shift == 0: the one bucket this partition is a slice of
-                // a bit that is already set needs no atomic: with few buckets (small b) every partition of a bucket
-                // would otherwise hit the same word, and same-address atomics serialise device-wide
+                // With few buckets (small b) every partition of a bucket would hit the same word, and same-address atomics
+                // serialise device-wide: there a bit that is already set is not set again (bits_check).  With many buckets
+                // the words are all different, and the read before the atomic would be a dependent load behind this
+                // partition's stores: the wave would sit out their whole round trip (it was a third of k_insert's time).
                 if (mask) {
                     if (nb >= 32) {
-                        if (lane * 32 < nb && (ix.bucket_bits[(first >> 5) + lane] & mask) != mask) atomicOr(&ix.bucket_bits[(first >> 5) + lane], mask);
+                        if (lane * 32 < nb && (!ix.bits_check || (ix.bucket_bits[(first >> 5) + lane] & mask) != mask)) atomicOr(&ix.bucket_bits[(first >> 5) + lane], mask);
                     } else if (lane == 0) {
                         const u32 bits = mask << (first & 31);
-                        if ((ix.bucket_bits[first >> 5] & bits) != bits) atomicOr(&ix.bucket_bits[first >> 5], bits);
+                        if (!ix.bits_check || (ix.bucket_bits[first >> 5] & bits) != bits) atomicOr(&ix.bucket_bits[first >> 5], bits);
                     }
                 }
             }
             d = dn;
             rr = rn;
+            PHASE(9)
         }
     }
+    PHASE_FLUSH
     if (lane == 0) {
         ix.slot_cur[blockIdx.x] = acur;
         ix.slot_end[blockIdx.x] = aend;
@@ -541,13 +720,15 @@ __device__ __forceinline__ void insert_body(const BriskParams& P, u64* __restric
 }
 
 
+template <u32 NW, u32 KB, u32 SHIFT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
                                                u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
-    insert_body<WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
+    insert_body<WI_MAX_INST, NW, KB, SHIFT>(P, rec, desc, n_touched, ix, work_counter);
 }
+template <u32 NW, u32 KB, u32 SHIFT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
                                                                                          u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
-    insert_body<2 * WI_MAX_INST>(P, rec, desc, n_touched, ix, work_counter);
+    insert_body<2 * WI_MAX_INST, NW, KB, SHIFT>(P, rec, desc, n_touched, ix, work_counter);
 }
 
 // bucket occupancy for partitions wider than 64 buckets (small part_bits): one pass over all entries
