@@ -362,6 +362,26 @@ __device__ __forceinline__ bool dedupe_records(u32 stride, const RecRegs& rr, u3
     return dup;
 }
 
+// a batch's work descriptors, one per lane (two 16-byte loads), and the broadcast of one of them through scalar registers
+struct BatchDescs {
+    uint4 a, b;
+};
+__device__ __forceinline__ BatchDescs load_batch_descs(const PartDesc* __restrict__ desc, u32 t) {
+    const uint4* p = reinterpret_cast<const uint4*>(desc + t);
+    return BatchDescs{p[0], p[1]};
+}
+__device__ __forceinline__ PartDesc batch_desc(const BatchDescs& m, u32 i) {  // i: wave-uniform lane index
+    PartDesc d;
+    d.part = (u32)__builtin_amdgcn_readlane((int)m.a.x, (int)i);
+    d.r_begin = (u32)__builtin_amdgcn_readlane((int)m.a.y, (int)i);
+    d.n_rec = (u32)__builtin_amdgcn_readlane((int)m.a.z, (int)i);
+    d.n_inst = (u32)__builtin_amdgcn_readlane((int)m.a.w, (int)i);
+    d.n_exist = (u32)__builtin_amdgcn_readlane((int)m.b.x, (int)i);
+    d.cap = (u32)__builtin_amdgcn_readlane((int)m.b.y, (int)i);
+    d.off = (unsigned long long)(u32)__builtin_amdgcn_readlane((int)m.b.z, (int)i) | ((unsigned long long)(u32)__builtin_amdgcn_readlane((int)m.b.w, (int)i) << 32);
+    return d;
+}
+
 // MAXI: k-mer instances per chunk.  256 (10 KB of LDS, 128 registers: 4 waves per SIMD) for the usual partitions of a
 // few hundred instances; 512 (2 waves per SIMD) when partitions are big -- few distinct minimizers, as with m <= 11 --
 // and the passes over a partition's entries saved by half as many chunks outweigh the occupancy.
@@ -405,18 +425,25 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
         // ---- take the next batch of partitions (one atomic per WI_BATCH partitions)
         u32 t0 = 0;
         if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
-        t0 = __shfl(t0, 0, 64);
+        t0 = (u32)__builtin_amdgcn_readfirstlane((int)t0);
         if (t0 >= n_touched) break;
         const u32 t_end = min(t0 + WI_BATCH, n_touched);
-        PartDesc d = desc[t0];
+        // The batch's descriptors, one per lane, stay in registers: a partition's descriptor is then eight
+        // v_readlane away (scalar registers), never a memory round trip -- and the NEXT partition's records can be
+        // requested at the top of the current one, a whole partition (several microseconds) ahead of their use.
+        // Under this kernel's own random traffic a dependent load takes 2-4 us of a partition's ~7 us.
+        const BatchDescs mine = load_batch_descs(desc, min(t0 + lane, n_touched - 1));
+        PartDesc d = batch_desc(mine, 0);
         RecRegs rr = load_rec_regs(P, rec, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane);
 
         for (u32 t = t0; t < t_end; t++) {
-            // descriptor of the partition after this one: in flight while this one is processed
             const u32 tn = t + 1;
             PartDesc dn{};
-            if (tn < t_end) dn = desc[tn];
-            RecRegs rn{0, 0, 0, 0, 0};
+            RecRegs rn{0, 0, 0, 0, 0};  // first records of the next partition
+            if (tn < t_end) {
+                dn = batch_desc(mine, tn - t0);
+                rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
+            }
 
             CNT(0, 1)
             const u32 part = d.part;
@@ -539,9 +566,6 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
                     }
                 }
                 wave_sync();
-                // the next partition's first records: requested now, consumed next iteration
-                if (rc == d.r_begin && tn < t_end) rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
-
                 // ---- 0/1. expand to entry keys and de-duplicate
                 PHASE(2)
                 u32 dbg_r = 0;
@@ -624,6 +648,12 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
                     }
                 }
                 wave_sync();
+#ifndef INSERT_NO_EARLY_WAIT
+                // The prefetched records are waited for HERE, before this chunk's stores are issued: vmcnt retires in issue
+                // order, so a wait placed behind the stores (the next partition's first use) would sit out the stores' round
+                // trip as well.  They were requested a partition's worth of work ago.
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
                 PHASE(6)
                 CNT(6, (n_new + 63) / 64)
                 CNT(7, n_new)
