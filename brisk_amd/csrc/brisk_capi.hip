@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ struct brisk_hip_index {
     u64 max_batch_reads = 0;
 
     double* d_coef = nullptr;
-    double* d_tabs = nullptr;   // coef[128] + decycling chunk tables, staged to LDS by k_scan2
+    double* d_tabs = nullptr;   // coef[128] + packed fixed-point decycling chunk tables (u64 bits), staged to LDS by k_scan2
     ScanCfg scfg{};
     u32 scan_waves = 0;         // waves per k_scan2 block
     size_t scan_lds = 0;
@@ -458,7 +459,7 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     } else {
         const u32 bt = h->scan_waves * 64;
         const dim3 grid(nblocks(n_items, bt)), block(bt);
-        // instantiations: chunk-table count nch = ceil((m-1)/4) (5: m 18..21, 4: m 14..17, 3: m 10..13, else generic) x mode x
+        // instantiations: chunk-table count nch = ceil(m/4) (6: m 21..23, 4: m 13..15, 3: m 9..11, else generic) x mode x
         // {k and m compile-time for the two common parameter sets, or from P}
 #define LAUNCH_SCAN2(NCH, MODE, KK, MM) \
     hipLaunchKernelGGL((k_scan2<NCH, MODE, KK, MM>), grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, cc)
@@ -469,10 +470,10 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
         else LAUNCH_SCAN2(NCH, 0, KK, MM);                 \
     }
         const u32 k = h->P.k, m = h->P.m;
-        if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(5, 63, 21)
+        if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(6, 63, 21)
         else if (k == 31 && m == 15) LAUNCH_SCAN2_MODES(4, 31, 15)  // the reference's default parameters (apps/counter.cpp:355)
         else if (k == 31 && m == 11) LAUNCH_SCAN2_MODES(3, 31, 11)
-        else if (h->scfg.nch == 5) LAUNCH_SCAN2_MODES(5, 0, 0)
+        else if (h->scfg.nch == 6) LAUNCH_SCAN2_MODES(6, 0, 0)
         else if (h->scfg.nch == 4) LAUNCH_SCAN2_MODES(4, 0, 0)
         else if (h->scfg.nch == 3) LAUNCH_SCAN2_MODES(3, 0, 0)
         else LAUNCH_SCAN2_MODES(0, 0, 0)
@@ -986,31 +987,36 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMemsetAsync(h->d_coef, 0, 128 * sizeof(double), h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_coef, coef_table, 4 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
         {
-            // decycling chunk tables (host, from the caller's libm table): 4 nts per chunk.
+            // decycling chunk tables (host, from the caller's libm table): 4 nts per chunk, both sums of a chunk in one u64.
             // R(x)      = sum_{i=0}^{m-2} coef[4(m-1-i) + nt_i(x)]          (Decycling.cpp:17-24)
             // R(rot(x)) = sum_{i=1}^{m-1} coef[4(m-i)   + nt_i(x)]          (rot: Decycling.cpp:41)
+            // low word: the chunk's share of R, in units of 2^-24, + CLS_BIAS; high word: its share of R(rot), two's complement
             ScanCfg& c = h->scfg;
             c.nlow = std::min<u32>(32, k);
             c.nlow1 = std::min<u32>(32, k - 1);
-            c.nch = (m - 1 + 3) / 4;
+            c.nch = (m + 3) / 4;
             c.qcap = 320;  // > 4 super-k-mers per lane before a mid-read flush
             if (const char* e = getenv("BRISK_SCAN_QCAP")) c.qcap = (u32)std::max(128, atoi(e));
-            const u32 n_tab = 128 + 2 * c.nch * 256;
+            const u32 n_tab = 128 + c.nch * 256;
             std::vector<double> tabs(n_tab, 0.0);
             for (u32 i = 0; i < 4u * m; i++) tabs[i] = coef_table[i];
             for (u32 ch = 0; ch < c.nch; ch++)
                 for (u32 v = 0; v < 256; v++) {
                     double a = 0.0, bsum = 0.0;
-                    for (u32 i = 4 * ch; i < 4 * ch + 4 && i + 1 < m; i++) a += coef_table[4 * (m - 1 - i) + ((v >> (2 * (i - 4 * ch))) & 3)];
-                    for (u32 i = 1 + 4 * ch; i < 5 + 4 * ch && i < m; i++) bsum += coef_table[4 * (m - i) + ((v >> (2 * (i - 1 - 4 * ch))) & 3)];
-                    tabs[128 + ch * 256 + v] = a;
-                    tabs[128 + (c.nch + ch) * 256 + v] = bsum;
+                    for (u32 i = 4 * ch; i < 4 * ch + 4 && i < m; i++) {
+                        const u32 nt = (v >> (2 * (i - 4 * ch))) & 3;
+                        if (i + 1 < m) a += coef_table[4 * (m - 1 - i) + nt];
+                        if (i >= 1) bsum += coef_table[4 * (m - i) + nt];
+                    }
+                    const int64_t af = llround(std::ldexp(a, 24)), bf = llround(std::ldexp(bsum, 24));
+                    const u64 word = (u64)(u32)(af + (int64_t)CLS_BIAS) | ((u64)(u32)(int32_t)bf << 32);
+                    memcpy(&tabs[128 + ch * 256 + v], &word, 8);
                 }
             HIPCHK(h, hipMalloc((void**)&h->d_tabs, n_tab * sizeof(double)));
             HIPCHK(h, hipMemcpyAsync(h->d_tabs, tabs.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             // LDS: the class tables once per block, an emit queue per wave.  Eight waves per block, two blocks per CU.
-            const size_t per_wave = (size_t)(2 * c.qcap) * 8, fixed = (size_t)(n_tab + 9) * 8;
+            const size_t per_wave = (size_t)(c.qcap + 96) * 8, fixed = (size_t)(n_tab + 9) * 8;  // queue + the lanes' read starts and tags
             const size_t lds_max = 160 * 1024;
             u32 wv = 8;  // 2 blocks per CU, 4 waves per SIMD; block sizes that are not a multiple of 4 waves place badly
             if (2 * (fixed + wv * per_wave) > lds_max) wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);  // big m: one block per CU
@@ -1022,7 +1028,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             if (h->scan_lds > lds_attr) {
                 lds_attr = h->scan_lds;
 #define SCAN2_FNS(NCH, KK, MM) (const void*)k_scan2<NCH, 0, KK, MM>, (const void*)k_scan2<NCH, 1, KK, MM>, (const void*)k_scan2<NCH, 2, KK, MM>
-                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(5, 0, 0), SCAN2_FNS(3, 31, 11), SCAN2_FNS(4, 31, 15), SCAN2_FNS(5, 63, 21)};
+                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(6, 0, 0), SCAN2_FNS(3, 31, 11), SCAN2_FNS(4, 31, 15), SCAN2_FNS(6, 63, 21)};
 #undef SCAN2_FNS
                 for (const void* fn : fns) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
             }
@@ -1660,7 +1666,7 @@ BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mme
     u64* d_x = (u64*)h->lookup_buf.p;
     u64* d_k = d_x + n;
     HIPCHK(h, hipMemcpyAsync(d_x, mmers, n * 8, hipMemcpyHostToDevice, h->stream));
-    const size_t lds = (size_t)(128 + 2 * h->scfg.nch * 256) * 8;
+    const size_t lds = (size_t)(128 + h->scfg.nch * 256) * 8;
     hipLaunchKernelGGL(k_debug_keys, dim3(nblocks(n, 256)), dim3(256), lds, h->stream, h->P, h->scfg.nch, h->d_tabs, d_x, n, exact, d_k);
     if ((rc = launch_check(h, "k_debug_keys"))) return rc;
     HIPCHK(h, hipMemcpyAsync(keys, d_k, n * 8, hipMemcpyDeviceToHost, h->stream));

@@ -296,47 +296,49 @@ __device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1u
 struct ScanCfg {
     u32 nlow;     // nts of a k-mer that get_minimizer sees: min(32, k)   (F2)
     u32 nlow1;    // same for the (k-1)-mer
-    u32 nch;      // 4-nt chunks of a decycling sum: ceil((m-1)/4)
+    u32 nch;      // 4-nt chunks of an m-mer: ceil(m/4)
     u32 qcap;     // emit queue entries per wave
 };
 
-// class from chunk tables: tabs[c][v] (R) and tabs[nch+c][v] (R of the rotation)
-template <int NCH>  // NCH > 0: compile-time chunk count (unrolled lookups); 0: runtime nch
-__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const double* tabs, const double* coef) {
-    double r = 0.0, rr = 0.0;
+// Decycling class from packed fixed-point chunk tables.  tabs[c * 256 + v] (one u64 per 4-nt chunk value) holds the
+// chunk's share of R(x) in its low word -- scaled by 2^24, biased by CLS_BIAS so that the low words of a whole sum
+// never carry -- and its share of R(rot(x)) in the high word (two's complement): ceil(m/4) look-ups and as many 64-bit
+// adds give both sums.  Every table word is rounded to a unit of 2^-24 (<= 0.5 unit of error each, <= 4 units per sum
+// for m <= 31; the reference's own FP64 fold is within 1e-5 unit of the exact value), eps = 1e-6 is 16.78 units: a sum
+// >= 21 is certainly > eps, a sum <= 12 certainly < eps, anything in [13, 20] (either sign) is decided by the exact
+// FP64 fold in the reference's order (decy_class).  Host side: build_class_tables in brisk_capi.hip.
+#define CLS_BIAS (1u << 28)
+#define CLS_HI 21
+#define CLS_LO 12
+template <int NCH>  // NCH > 0: compile-time chunk count (unrolled look-ups); 0: runtime nch
+__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const u64* tabs, const double* coef) {
+    u64 acc = tabs[(u32)x & 255];
     if (NCH > 0) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
-            rr += tabs[(NCH + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
-        }
+        for (int c = 1; c < NCH; c++) acc += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
     } else {
-        for (u32 c = 0; c < nch; c++) {
-            r += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
-            rr += tabs[(nch + c) * 256 + (u32)((x >> (8 * c + 2)) & 255)];
-        }
+        for (u32 c = 1; c < nch; c++) acc += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
     }
-    const double eps = 0.000001, g = 1e-9;
-    // any summation order is within ~1e-13 of the reference's fold; inside the guard band redo it exactly
-    if (fabs(fabs(r) - eps) < g || fabs(fabs(rr) - eps) < g) return decy_class(x, m, coef);
-    if (r > eps) return rr < eps ? 0u : 2u;
-    if (r < -eps) return rr > -eps ? 1u : 2u;
-    return 2u;
+    const int a = (int)((u32)acc - (NCH > 0 ? (u32)NCH : nch) * CLS_BIAS), b = (int)(u32)(acc >> 32);
+    const u32 ua = (u32)(a < 0 ? -a : a), ub = (u32)(b < 0 ? -b : b);
+    if (ua - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2) || ub - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2)) return decy_class(x, m, coef);
+    const bool c0 = a >= CLS_HI && b <= CLS_LO, c1 = a <= -CLS_HI && b >= -CLS_LO;
+    return c0 ? 0u : c1 ? 1u : 2u;
 }
 template <int NCH = 0>
-__device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, const double* tabs, const double* coef) {
+__device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, const u64* tabs, const double* coef) {
     return ((u64)decy_class_fast<NCH>(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
 }
 
 __global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, const double* __restrict__ g_tabs, const u64* __restrict__ x, u64 n,
                                                     int exact, u64* __restrict__ out) {
     extern __shared__ double smem_d[];
-    const u32 n_tab = 128 + 2 * nch * 256;
+    const u32 n_tab = 128 + nch * 256;
     for (u32 i = threadIdx.x; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
     __syncthreads();
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, smem_d + 128, smem_d);
+    out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, (const u64*)(smem_d + 128), smem_d);
 }
 
 // value of a wave-uniform lane, through SGPRs
@@ -541,9 +543,19 @@ __device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first
     }
 }
 
+// Emit queue entry (one u64 per closed super-k-mer): low word = the step (k-mer index in the lane's read) of its first
+// k-mer; high word = n | idx_end << 8 | reversed << 16 | (returned minimizer == 0) << 17 | lane << 18.  The lane's read
+// (stream index of its first nt, and its tag) is looked up in the wave's s_q0 / s_tag when the record is built.
+__device__ __forceinline__ void emit_queued(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, u64 ent, const u64* s_q0, const u32* s_tag,
+                                            unsigned long long slot) {
+    const u32 mi = (u32)(ent >> 32), src = (mi >> 18) & 63u;
+    const u64 q_start = s_q0[src] + (u32)ent;
+    emit_record_at(P, packed, q_start, 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, s_tag[src], q_start | ((u64)((mi >> 17) & 1) << 63), slot);
+}
+
 // what is left in the waves' queues when their reads end: one slot reservation for the whole block
-__device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, const u64* q_start,
-                                                 const u32* q_misc, const u32* q_tag, u32 qcount, u32* s_wcnt, unsigned long long* s_wbase) {
+__device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, const u64* q_ent, const u64* s_q0,
+                                                 const u32* s_tag, u32 qcount, u32* s_wcnt, unsigned long long* s_wbase) {
     const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (lane == 0) s_wcnt[wid] = qcount;
     __syncthreads();
@@ -555,10 +567,22 @@ __device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32
     __syncthreads();
     unsigned long long base = *s_wbase;
     for (u32 i = 0; i < wid; i++) base += s_wcnt[i];
-    for (u32 e = lane; e < qcount; e += 64) {
-        const u32 mi = q_misc[e];
-        emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], q_start[e] | ((u64)((mi >> 17) & 1) << 63), base + e);
+    for (u32 e = lane; e < qcount; e += 64) emit_queued(P, packed, out, q_ent[e], s_q0, s_tag, base + e);
+}
+
+// minimum of x over the lane's 16-lane row, in every lane of the row (DPP row rotations: one instruction per step)
+__device__ __forceinline__ u32 row_min_u32(u32 x) {
+#define ROW_MIN_STEP(CTRL)                                                                      \
+    {                                                                                           \
+        const u32 y_ = (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false); \
+        x = y_ < x ? y_ : x;                                                                    \
     }
+    ROW_MIN_STEP(0x128)  // row_ror:8
+    ROW_MIN_STEP(0x124)  // row_ror:4
+    ROW_MIN_STEP(0x122)  // row_ror:2
+    ROW_MIN_STEP(0x121)  // row_ror:1
+#undef ROW_MIN_STEP
+    return x;
 }
 
 // MODE 0: reads, insert; 1: reads, query (stops a read at a returned minimizer of 0); 2: virtual reads (chunks of long sequences)
@@ -569,20 +593,20 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
                                                 u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, ChunkCtl cc) {
     constexpr bool VR = MODE == 2, query_mode = MODE == 1;
     extern __shared__ double smem_d[];
-    double* s_coef = smem_d;             // 128
-    double* s_tabs = smem_d + 128;       // 2*nch*256
+    const double* s_coef = smem_d;                        // 128
+    const u64* s_tabs = (const u64*)(smem_d + 128);       // nch*256 packed fixed-point chunk sums
     const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const u32 n_tab = 128 + 2 * (NCH ? (u32)NCH : cfg.nch) * 256;
+    const u32 n_tab = 128 + (NCH ? (u32)NCH : cfg.nch) * 256;
     for (u32 i = tid; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
     unsigned long long* s_wbase = (unsigned long long*)(smem_d + n_tab);      // block's slot base at the final flush
     u32* s_wcnt = (u32*)(s_wbase + 1);                                         // [16] records left per wave
-    u64* q_start = (u64*)(smem_d + n_tab + 9) + (size_t)wid * (2 * cfg.qcap);  // [qcap] stream index of the super-k-mer's first nt
-    u32* q_misc = (u32*)(q_start + cfg.qcap);      // [qcap] n | idx_end<<8 | rev<<16
-    u32* q_tag = q_misc + cfg.qcap;                // [qcap] read index
-    __syncthreads();
+    u64* q_ent = (u64*)(smem_d + n_tab + 9) + (size_t)wid * (cfg.qcap + 96);   // [qcap] the wave's emit queue
+    u64* s_q0 = q_ent + cfg.qcap;                  // [64] stream index of every lane's first nt
+    u32* s_tag = (u32*)(s_q0 + 64);                // [64] every lane's tag (read index, or chunk slot)
 
     const u32 k = KK ? (u32)KK : P.k, m = MM ? (u32)MM : P.m, w = k - m, nch = NCH ? (u32)NCH : cfg.nch;
     const u64 M = MM ? ((1ull << (2 * MM)) - 1) : P.m_mask;
+    const u32 ksh = 2 * m > 30 ? 2 * m - 30 : 0;  // the mix's bits below its top 30
     const u32 nlow = k < 32 ? k : 32, nlow1 = k - 1 < 32 ? k - 1 : 32;  // nts of a k-mer / (k-1)-mer that get_minimizer sees (F2)
     const u64 r = (u64)blockIdx.x * blockDim.x + tid;
     u64 q0 = 0, len = 0;
@@ -605,6 +629,9 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             if (cc.long_limit && len >= k && len - k + 1 > cc.long_limit) len = 0;  // a chunked launch takes this one
         }
     }
+    s_q0[lane] = q0;
+    s_tag[lane] = tagval;
+    __syncthreads();
     const bool live = len >= k;  // counter.cpp:233-235
     u32 nk = live ? (u32)(len - k + 1) : 0;
     u32 max_nk = nk;
@@ -613,17 +640,16 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         max_nk = y > max_nk ? y : max_nk;
     }
     if (max_nk == 0) {  // nothing to scan in this wave; it still takes part in the block's final reservation
-        scan_final_flush(P, packed, out, q_start, q_misc, q_tag, 0, s_wcnt, s_wbase);
+        scan_final_flush(P, packed, out, q_ent, s_q0, s_tag, 0, s_wcnt, s_wbase);
         return;
     }
     const u64 KEY0 = order_key_fast<NCH>(0, m, M, nch, s_tabs, s_coef);
     const u64 KEY0s = read_lane_u64(KEY0, 0);  // the same value, in scalar registers
 
     // ---- prologue: the low 64 bits of the (k-1)-mer; its last m-mer seeds the rolling candidates
-    u64 cf = 0, cr = 0, low64 = 0;
+    u64 cr = 0, low64 = 0;
     if (live) low64 = load_nts(packed, q0 + (k - 1) - nlow1, nlow1);
-    cf = low64 & M;
-    cr = rc64(cf, m);
+    cr = rc64(low64 & M, m);
 
     // ---- minimizer of the (k-1)-mer (Kmers.cpp:533): every lane at once, windows in lockstep
     u64 mini_hash;
@@ -674,12 +700,15 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     }
     bool foreign = seeded;  // the vector open at a seeded start began before it: it is the previous chunk's
 
-    // ---- the stream of k-mers
+    // ---- the stream of k-mers.  Per lane: the open vector started at step p0; the minimizer sits mini_pos nts into the
+    // current k-mer (counted while the lane is active only).  A vector's idx values follow from these when it closes:
+    // the minimizer_idx of k-mer j of the vector is mp0 + j (forward) or w - mp0 - j (reversed), mp0 = mini_pos at p0.
     u32 qcount = 0;  // wave-uniform
-    u32 n = 0, p0 = 0, first_idx = 0, last_idx = 0, n_emitted = 0;
+    u32 p0 = 0, n_emitted = 0;
     bool dead = false;
     u64 buf = 0;
     const u32 Km = k - m;
+    const u32 lane_bits = lane << 18;
     for (u32 p = 0; p < max_nk; p++) {
         const bool act = p < nk && !dead;
         if (VR && live) {  // the enumerator state before step p, for the chunk-seam check
@@ -693,30 +722,31 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         }
         const u32 c = (u32)(buf >> 62);
         buf <<= 2;
-        cf = ((cf << 2) + c) & M;
         cr = (cr >> 2) + ((u64)(c ^ 2u) << (2 * m - 2));
         low64 = (low64 << 2) | c;
+        const u64 cf = low64 & M;
         const bool revf = cr < cf;
         const u64 h = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
-        mini_pos++;
+        mini_pos += act ? 1u : 0u;
         const bool expired = act && mini_pos > w;                  // Kmers.cpp:551
         const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
         const bool closed = expired || newmin;
         // the vector closed by this step (Kmers.cpp:585-588); a close at p == 0 is ignored (:590-592)
         bool push = closed && p > 0 && !foreign && p0 >= emit_from && p0 < emit_until;  // a chunk emits the vectors that start in its window
         if (closed) foreign = false;
-        if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) {  // counter.cpp:304-306: returned minimizer == 0
+        if (query_mode && push && n_emitted > 0 && mini_hash == KEY0) {  // counter.cpp:304-306: returned minimizer == 0
             push = false;
             dead = true;
         }
         {
             const unsigned long long bal = __ballot(push);
             if (push) {
-                const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
-                q_start[at] = q0 + p0;
-                q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17);
-                q_tag[at] = tagval;
-                n_emitted++;
+                const u32 n = p - p0;
+                // minimizer_idx of the LAST element of the returned vector (reversed vectors are returned back to front)
+                const u32 idx_end = reversed ? w + n - mini_pos : mini_pos - 1;
+                const u32 hi = n | (idx_end << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17) | lane_bits;
+                q_ent[qcount + (u32)__popcll(bal & lanes_below(lane))] = ((u64)hi << 32) | p0;
+                if (query_mode) n_emitted++;
             }
             qcount += (u32)__popcll(bal);
         }
@@ -741,19 +771,33 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             const u64 rcv = rc64(fwd, m);
             const bool rv = rcv < fwd;
             u64 key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
-            if (wl > Km || wl >= nlow) key = ~0ull;
-            u64 hm = key;  // minimum of this lane's half
-            for (int o = 16; o > 0; o >>= 1) {
-                const u64 y = __shfl_xor(hm, o, 64);
-                hm = y < hm ? y : hm;
+            // an order-preserving 32-bit prefix of the key (class, then the top 30 bits of the mix): the half's minimum goes
+            // over the DPP network on it; two windows agreeing on all 32 bits are told apart by the 64-bit path below
+            u32 k32 = ((u32)(key >> 62) << 30) | (u32)((key & M) >> ksh);
+            if (wl > Km || wl >= nlow) {
+                key = ~0ull;
+                k32 = ~0u;
             }
-            const unsigned long long tie = __ballot(key == hm);
+            const u32 rm = row_min_u32(k32);
+            const u32 r0 = (u32)__builtin_amdgcn_readlane((int)rm, 0), r1 = (u32)__builtin_amdgcn_readlane((int)rm, 16);
+            const u32 r2 = (u32)__builtin_amdgcn_readlane((int)rm, 32), r3 = (u32)__builtin_amdgcn_readlane((int)rm, 48);
+            const u32 mA = r0 < r1 ? r0 : r1, mB = r2 < r3 ? r2 : r3;
+            unsigned long long tie = __ballot(k32 == (lane < 32 ? mA : mB));
             const unsigned long long rvb = __ballot(rv);
+            const bool unique = __popc((u32)tie) == 1 && (!two || __popc((u32)(tie >> 32)) == 1);  // wave-uniform
+            u64 hm = key;  // slow path only: minimum of this lane's half on the full keys
+            if (!unique) {
+                for (int o = 16; o > 0; o >>= 1) {
+                    const u64 y = __shfl_xor(hm, o, 64);
+                    hm = y < hm ? y : hm;
+                }
+                tie = __ballot(key == hm);
+            }
             for (int half = 0; half < (two ? 2 : 1); half++) {  // wave-uniform, scalar work
                 const int L = half ? LB : LA;
                 const u32 t = (u32)(tie >> (32 * half)), rb = (u32)(rvb >> (32 * half));
-                u64 hmin = read_lane_u64(hm, 32 * half);
                 u32 first = (u32)__ffs((int)t) - 1, last = 31u - (u32)__clz((int)t);
+                u64 hmin = unique ? read_lane_u64(key, 32 * half + (int)first) : read_lane_u64(hm, 32 * half);
                 bool rf = (rb >> first) & 1, rl = (rb >> last) & 1;
                 if (Km >= 32) {  // windows 32..Km: the all-A m-mer
                     if (KEY0s < hmin) {
@@ -788,42 +832,31 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             mini_pos = 0;
             reversed = revf;
         }
-        if (act) {
-            const u32 idx = reversed ? w - mini_pos : mini_pos;  // Kmers.cpp:578-584
-            if (closed && (p > 0 || seeded)) n = 0;  // a close at a seeded start is a real one: a new vector begins here
-            if (n == 0) {
-                p0 = p;
-                first_idx = idx;
-            }
-            last_idx = idx;
-            n++;
-        }
+        // a new vector begins with this k-mer (Kmers.cpp:578-592; a close at a seeded start is a real one)
+        if (closed && (p > 0 || seeded)) p0 = p;
         // turn queued super-k-mers into records with full waves.  All waves append to one record counter, and
         // same-address atomics serialise device-wide (~15 ns each): one reservation per flush, not per record
         if (qcount + 64 > cfg.qcap) {
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)qcount);
             base = read_lane_u64(base, 0);
-            for (u32 e = lane; e < qcount; e += 64) {
-                const u32 mi = q_misc[e];
-                emit_record_at(P, packed, q_start[e], 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, q_tag[e], q_start[e] | ((u64)((mi >> 17) & 1) << 63), base + e);
-            }
+            for (u32 e = lane; e < qcount; e += 64) emit_queued(P, packed, out, q_ent[e], s_q0, s_tag, base + e);
             qcount = 0;
         }
     }
     // the last vector of every read (Kmers.cpp:596-601)
     {
         // the sequence's true end closes the open vector; it belongs to the chunk in whose window it started
-        bool push = live && !dead && n > 0 && seq_last && !foreign && p0 >= emit_from && p0 < emit_until;
+        bool push = live && !dead && nk > p0 && seq_last && !foreign && p0 >= emit_from && p0 < emit_until;
         if (push && query_mode && n_emitted > 0 && mini_hash == KEY0) push = false;
         const unsigned long long bal = __ballot(push);
         if (push) {
-            const u32 at = qcount + (u32)__popcll(bal & lanes_below(lane));
-            q_start[at] = q0 + p0;
-            q_misc[at] = n | ((reversed ? first_idx : last_idx) << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17);
-            q_tag[at] = tagval;
+            const u32 n = nk - p0;
+            const u32 idx_end = reversed ? w + n - 1 - mini_pos : mini_pos;  // mini_pos: of the read's last k-mer
+            const u32 hi = n | (idx_end << 8) | ((reversed ? 1u : 0u) << 16) | ((mini_hash == KEY0 ? 1u : 0u) << 17) | lane_bits;
+            q_ent[qcount + (u32)__popcll(bal & lanes_below(lane))] = ((u64)hi << 32) | p0;
         }
         qcount += (u32)__popcll(bal);
     }
-    scan_final_flush(P, packed, out, q_start, q_misc, q_tag, qcount, s_wcnt, s_wbase);
+    scan_final_flush(P, packed, out, q_ent, s_q0, s_tag, qcount, s_wcnt, s_wbase);
 }
