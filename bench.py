@@ -10,6 +10,9 @@ which are generated ON DEVICE, packed 2-bit, before the timed region starts.
             to the owner of their bucket range with ONE all-to-all (RCCL over
             xGMI) and inserts what it owns.  value = entries created by all
             ranks / max-over-ranks time.
+    --scaling strong : the job is fixed instead -- --reads reads in all, rank r scans
+            reads [r, r+1) * reads / N of the SAME genome -- so that value(N) / value(1)
+            is the strong-scaling speed-up BASELINE.json's target is quoted in.
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
 python -m torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from env).
 """
@@ -40,14 +43,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU per step (weak scaling) or in the whole job (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: --reads per GPU; strong: --reads in all, split over the GPUs")
     ap.add_argument("--k", type=int, default=63)
     ap.add_argument("--m", type=int, default=21)
     ap.add_argument("--b", type=int, default=14)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--coverage", type=float, default=15.0)
     ap.add_argument("--part-bits", type=int, default=0, help="log2(#partitions); 0: library default")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000, help="reads of the CPU baseline sample (about 15 s of the reference on the box's host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
@@ -79,8 +83,14 @@ def main():
             dist.init_process_group(args.backend)
 
     k, m, b, L = args.k, args.m, args.b, args.read_len
-    n_reads = args.reads
-    total_reads = n_reads * N
+    if args.scaling == "strong":  # one fixed job: this rank's contiguous share of its reads
+        total_reads = args.reads
+        first_read = total_reads * rank // N
+        n_reads = total_reads * (rank + 1) // N - first_read
+    else:
+        n_reads = args.reads
+        total_reads = n_reads * N
+        first_read = rank * n_reads
     genome_len = max(int(total_reads * L / args.coverage), L + 1)
     stream = torch.cuda.Stream(device=dev)
     sptr = stream.cuda_stream
@@ -97,7 +107,7 @@ def main():
         d_starts = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     gen = brisk_amd.BriskHip(k, m, b, device=dev_index, stream=sptr, part_bits=2)
     stream.synchronize()
-    gen.synth_reads(genome_len, rank * n_reads, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())
+    gen.synth_reads(genome_len, first_read, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())
     gen.sync()
     gen.close()
 
@@ -163,13 +173,13 @@ def main():
         roofline = None
         if dom:
             launches_per_step = hot[dom]["launches"] / args.steps
-            reads_per_launch = n_reads / launches_per_step
+            reads_per_launch = n_reads / launches_per_step  # rank 0's share (all shares are equal to within one read)
             avg_ms = hot[dom]["ms"] / hot[dom]["launches"]
             n_skm = 4.17 if (k, m) == (63, 21) else 11.1
             bytes_per_launch = b_alg(k, m, b, L, n_skm) * reads_per_launch
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, k, m, b, n_reads),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic(dom, k, m, b, n_reads),
                         "avg_launch_ms": round(avg_ms, 3), "alg_bytes_per_read": b_alg(k, m, b, L, n_skm),
                         "kernels_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in prof.items() if v["launches"]}}
         cpu = None
@@ -178,10 +188,11 @@ def main():
         line = {
             "metric": "distinct k-mers indexed/sec (k=%d,m=%d)" % (k, m), "value": round(value, 1), "unit": "k-mers/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%dx MI355X: %dM synthetic %d bp reads per GPU, k=%d m=%d b=%d, uint8 counts, %gx coverage"
-                                   % (N, n_reads // 1_000_000, L, k, m, b, args.coverage),
-                       "reads_per_gpu": n_reads, "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%dx MI355X: %s synthetic %d bp reads %s, k=%d m=%d b=%d, uint8 counts, %gx coverage"
+                                   % (N, ("%dM" % (args.reads // 1_000_000)) if args.reads >= 1_000_000 else str(args.reads), L,
+                                      "per GPU" if args.scaling == "weak" else "in all", k, m, b, args.coverage),
+                       "reads_per_gpu": n_reads, "total_reads": total_reads, "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
                        "parallelism": "bucket-range shard x%d + all-to-all" % N if N > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -192,25 +203,46 @@ def main():
 
 
 def pmc_traffic(kernel, k, m, b, n_reads):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes, KiB, uncorrected --
-    on gfx950 FETCH_SIZE under-reports reads).  None when the committed passes
-    were taken on another workload: PMC counters cannot be collected from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes, KiB), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, WRITE_SIZE as is).
+    PMC counters cannot be collected from inside this process, so the number is only as good as the passes are current:
+    it is reported only when the JSON was taken on this workload AND on kernel sources that hash to what is in the
+    tree now (tools/src_hash.py); otherwise traffic is null and traffic_note says which of the two failed."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    w = d.get("workload", {})
-    if (w.get("k"), w.get("m"), w.get("b"), w.get("reads")) != (k, m, b, n_reads):
-        return None
-    kernels = d.get("kernels", {})
-    # the scan is a template: its profile name carries the instantiation (k_scan2<nch, mode, k, m>)
-    name = next((n for n in kernels if n.startswith("k_scan2<")), kernel) if kernel == "k_scan" else kernel
-    e = kernels.get(name)
-    if not e or not e.get("launches"):
-        return None
-    return round((e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024 / e["launches"])
+        from src_hash import kernel_source_hash
+        now = kernel_source_hash(ROOT)
+    except Exception as e:  # noqa: BLE001
+        return {"traffic": None, "traffic_note": "kernel sources not hashable: %s" % e}
+    why = "no profiles/*_pmc_traffic.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        w = d.get("workload", {})
+        if (w.get("k"), w.get("m"), w.get("b"), w.get("reads")) != (k, m, b, n_reads):
+            why = "committed PMC passes are of another workload"
+            continue
+        if d.get("kernel_source_sha256") != now:
+            why = "committed PMC passes (%s) were taken on other kernel sources (%s..., now %s...)" % (
+                os.path.basename(path), str(d.get("kernel_source_sha256"))[:12], now[:12])
+            continue
+        kernels = d.get("kernels", {})
+        # templates carry their instantiation in the profile name (k_scan2<...>, k_insert<...>)
+        pref = {"k_scan": "k_scan2<", "k_insert": "k_insert"}.get(kernel, kernel)
+        name = next((n for n in kernels if n.startswith(pref)), None)
+        e = kernels.get(name) if name else None
+        if not e or not e.get("launches"):
+            why = "kernel %s not in %s" % (kernel, os.path.basename(path))
+            continue
+        corr = d.get("correction", {})
+        raw = (e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024 / e["launches"]
+        cor = (e.get("FETCH_SIZE", 0) * corr.get("FETCH_SIZE", 1.0) + e.get("WRITE_SIZE", 0) * corr.get("WRITE_SIZE", 1.0)) * 1024 / e["launches"]
+        return {"traffic": round(cor), "traffic_raw": round(raw), "traffic_source": os.path.basename(path), "traffic_kernel": name}
+    return {"traffic": None, "traffic_note": why}
 
 
 def cpu_baseline(k, m, b, L, coverage, sample_reads):

@@ -2,18 +2,26 @@
 // apps/counter.cpp, which compiles unchanged against brisk_amd/include and is built by the tests).
 //   brisk_count --facade FASTA k m b [dump.txt]   per-call API: SuperKmerEnumerator + Brisk<uint8_t>
 //   brisk_count --bulk   FASTA k m b [dump.txt]   bulk C-ABI: brisk_hip_insert_reads, FASTA or FASTA.gz streamed in batches
-// Prints nb_kmers / nb_buckets / sum of counts; optionally dumps "KMER idx count" lines.
+//   brisk_count --mixed  FASTA k m b              BASELINE config #5's protocol (apps/counter.cpp:197-227,314-346): one thread streams the
+//                                                 file into brisk_hip_insert_reads while a second thread issues brisk_hip_get_reads on
+//                                                 the first reads of batches that are already in; prints what every get saw
+// Prints nb_kmers / nb_buckets / sum of counts; optionally dumps "KMER idx count" lines (dump.txt, "-" for none) and
+// writes the index as a KFF file (a 7th argument: BriskWriter in --facade mode, brisk_write_kff in --bulk mode).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "Brisk.hpp"
 #include "brisk_fasta.hpp"
+#include "writer.hpp"
 
 static std::vector<std::string> read_fasta(const char* path) {
     std::vector<std::string> out;
@@ -27,17 +35,98 @@ static std::vector<std::string> read_fasta(const char* path) {
     return out;
 }
 
+// --mixed: concurrent insert + get on ONE handle from two host threads (include/brisk_hip.h, "Threads").
+// Output, one line each: "batch J N" (batch J of N reads is in), "get J s0 s1 ..." (the per-read sums a get of batch J's
+// first reads returned while later batches were being inserted), "final J s0 ..." (the same get after the last batch),
+// "digest ENTRIES SUM DIGEST" (brisk_hip_checksum of the final index).
+static int run_mixed(const char* path, uint8_t k, uint8_t m, uint8_t b, const double* coef, size_t batch_bases) {
+    const size_t sample_reads = getenv("BRISK_MIXED_SAMPLE") ? (size_t)atoll(getenv("BRISK_MIXED_SAMPLE")) : 50;
+    brisk_hip_options o{};
+    o.struct_size = sizeof o;
+    brisk_hip_index* h = nullptr;
+    if (brisk_hip_create(&h, k, m, b, 1, coef, &o) != BRISK_HIP_OK) return 1;
+    struct Sample {
+        std::string flat;
+        std::vector<uint64_t> offs;
+    };
+    std::mutex mu;
+    std::vector<Sample> samples;  // sample j = the first reads of batch j, published once batch j is in
+    std::vector<std::string> log;
+    std::atomic<bool> done{false}, failed{false};
+    auto query = [&](size_t j, const char* tag) {
+        Sample s;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            s = samples[j];
+        }
+        std::vector<uint64_t> sums(s.offs.size() - 1);
+        if (brisk_hip_get_reads(h, s.flat.data(), s.offs.data(), sums.size(), sums.data()) != BRISK_HIP_OK) {
+            failed = true;
+            return;
+        }
+        std::string line = std::string(tag) + " " + std::to_string(j);
+        for (uint64_t v : sums) line += " " + std::to_string(v);
+        std::lock_guard<std::mutex> g(mu);
+        log.push_back(line);
+    };
+    std::thread getter([&]() {
+        size_t last = (size_t)-1;
+        while (!done && !failed) {
+            size_t have;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                have = samples.size();
+            }
+            if (have == 0 || have - 1 == last) {
+                std::this_thread::yield();
+                continue;
+            }
+            last = have - 1;
+            query(last, "get");
+        }
+    });
+    FastaBatcher batches(path, batch_bases);
+    FastaBatch bt;
+    size_t j = 0;
+    while (!failed && batches.next(bt)) {
+        if (brisk_hip_insert_reads(h, bt.flat.data(), bt.offs.data(), bt.size()) != BRISK_HIP_OK) {
+            std::cerr << brisk_hip_last_error(h) << std::endl;
+            failed = true;
+            break;
+        }
+        Sample s;
+        const size_t ns = std::min(sample_reads, bt.size());
+        s.flat = bt.flat.substr(0, bt.offs[ns]);
+        s.offs.assign(bt.offs.begin(), bt.offs.begin() + ns + 1);
+        std::lock_guard<std::mutex> g(mu);
+        samples.push_back(s);
+        log.push_back("batch " + std::to_string(j++) + " " + std::to_string(bt.size()));
+    }
+    done = true;
+    getter.join();
+    for (size_t q = 0; q < samples.size() && !failed; q++) query(q, "final");
+    uint64_t ck[3] = {0, 0, 0};
+    if (!failed && brisk_hip_checksum(h, ck) != BRISK_HIP_OK) failed = true;
+    brisk_hip_destroy(h);
+    for (const std::string& l : log) std::cout << l << "\n";
+    std::cout << "digest " << ck[0] << " " << ck[1] << " " << ck[2] << std::endl;
+    return failed ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 6) {
-        std::cerr << "usage: brisk_count --facade|--bulk FASTA k m b [dump.txt]" << std::endl;
+        std::cerr << "usage: brisk_count --facade|--bulk|--mixed FASTA k m b [dump.txt]" << std::endl;
         return 2;
     }
     const bool bulk = !strcmp(argv[1], "--bulk");
     const size_t batch_bases = getenv("BRISK_BATCH_BASES") ? (size_t)atoll(getenv("BRISK_BATCH_BASES")) : ((size_t)256 << 20);
-    const std::vector<std::string> seqs = bulk ? std::vector<std::string>() : read_fasta(argv[2]);
+    const bool mixed = !strcmp(argv[1], "--mixed");
+    const std::vector<std::string> seqs = (bulk || mixed) ? std::vector<std::string>() : read_fasta(argv[2]);
     const uint8_t k = (uint8_t)atoi(argv[3]), m = (uint8_t)atoi(argv[4]), b = (uint8_t)atoi(argv[5]);
-    const char* dump = argc > 6 ? argv[6] : nullptr;
+    const char* dump = argc > 6 && strcmp(argv[6], "-") ? argv[6] : nullptr;
+    const char* kff = argc > 7 ? argv[7] : nullptr;
     Parameters params(k, m, b);
+    if (mixed) return run_mixed(argv[2], k, m, b, params.dede->coef(), batch_bases);
     std::vector<std::string> lines;
     uint64_t nb_buckets = 0, nb_skmers = 0, nb_kmers = 0, mem = 0, largest = 0, sum = 0;
     try {
@@ -82,6 +171,11 @@ int main(int argc, char** argv) {
                 if (dump) lines.push_back(kmer2str(km.kmer_s, k) + " " + std::to_string(km.minimizer_idx) + " " + std::to_string(*c));
             }
             index.stats(nb_buckets, nb_skmers, nb_kmers, mem, largest);
+            if (kff) {  // apps/counter.cpp:407-411
+                BriskWriter writer(kff);
+                writer.write(index);
+                writer.close();
+            }
         } else {
             brisk_hip_options o{};
             o.struct_size = sizeof o;
@@ -113,6 +207,10 @@ int main(int argc, char** argv) {
                     sum += cnt[i];
                     if (dump) lines.push_back(kmer2str(((kint)hi[i] << 64) | lo[i], k) + " " + std::to_string(idx[i]) + " " + std::to_string(cnt[i]));
                 }
+            }
+            if (kff && brisk_write_kff(h, kff) != BRISK_HIP_OK) {
+                std::cerr << "KFF: " << brisk_hip_last_error(h) << std::endl;
+                return 1;
             }
             brisk_hip_destroy(h);
         }

@@ -52,6 +52,7 @@ struct brisk_hip_index {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    std::recursive_mutex call_mu;  // one call at a time per handle: the batch-granular lock of include/brisk_hip.h, "Threads"
     u64 n_parts = 0, n_buckets = 0;
     u64 max_batch_reads = 0;
 
@@ -1112,6 +1113,7 @@ BRISK_API int brisk_hip_destroy(brisk_hip_index* h) {
 BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     const u64 np = h->n_parts;
     HIPCHK(h, hipMemsetAsync(h->ix.dir, 0, np * sizeof(DirEnt), h->stream));
     HIPCHK(h, hipMemsetAsync(h->ix.cursor, 0, 8, h->stream));
@@ -1141,6 +1143,7 @@ static int check_device_flags(brisk_hip_index* h) {
 BRISK_API int brisk_hip_sync(brisk_hip_index* h) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     return check_device_flags(h);
 }
 
@@ -1164,6 +1167,7 @@ BRISK_API int brisk_hip_insert_packed(brisk_hip_index* h, const uint32_t* d_pack
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "insert_packed on a sharded index: use scan/route/insert_records");
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     return insert_packed_impl(h, d_packed, d_starts, n_reads);
 }
 
@@ -1172,6 +1176,7 @@ BRISK_API int brisk_hip_insert_reads(brisk_hip_index* h, const char* bases, cons
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "insert_reads on a sharded index: use scan/route/insert_records");
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     return for_each_host_batch(h, bases, offsets, n_reads, [&](u64, u64 nr) {
         return insert_packed_impl(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, nr);
     });
@@ -1181,6 +1186,7 @@ BRISK_API int brisk_hip_get_reads(brisk_hip_index* h, const char* bases, const u
     if (!h || (n_reads && (!bases || !offsets || !per_read_sum))) return BRISK_HIP_EINVAL;
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "get_reads on a sharded index sees one bucket range only: use scan_query / route_tagged / query_records");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     return for_each_host_batch(h, bases, offsets, n_reads, [&](u64 r0, u64 nr) -> int {
         int rc;
         if ((rc = ensure(h, h->sums_tmp, nr * 8))) return rc;
@@ -1198,6 +1204,7 @@ BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, cons
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "lookup on a sharded index sees one bucket range only: use scan_query / route_tagged / query_records");
     if (n == 0) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc;
     if ((rc = ensure(h, h->lookup_buf, n * 19 + 64))) return rc;
     char* base = (char*)h->lookup_buf.p;
@@ -1225,6 +1232,7 @@ static int enumerate_impl(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo
     if (!h || !cursor || !n_out || (cap && (!out_lo || !out_hi || !out_minimizer_idx))) return BRISK_HIP_EINVAL;
     if (out_ids && !h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "not an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     *n_out = 0;
     if (*cursor == 0 || !h->dir_snapshot_valid) {
         h->h_dir_cnt.resize(h->n_parts);
@@ -1289,6 +1297,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
                               uint64_t* largest_bucket) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     {
         int rcf = check_device_flags(h);
         if (rcf) return rcf;
@@ -1323,6 +1332,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
 BRISK_API int brisk_hip_checksum(brisk_hip_index* h, uint64_t out[3]) {
     if (!h || !out) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 24, h->stream));
     hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, h->stream, h->P, h->ix, (u32)h->n_parts, h->d_small);
     int rc;
@@ -1339,6 +1349,7 @@ BRISK_API int brisk_hip_checksum(brisk_hip_index* h, uint64_t out[3]) {
 BRISK_API int brisk_hip_scan_bound(brisk_hip_index* h, const uint64_t* d_starts, uint64_t n_reads, uint64_t* bound) {
     if (!h || !bound || (n_reads && !d_starts)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     *bound = 0;
     if (!n_reads) return BRISK_HIP_OK;
     u64 b = 0;
@@ -1351,6 +1362,7 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
                                     uint64_t cap_records, uint64_t* n_records) {
     if (!h || !n_records || (n_reads && (!d_packed || !d_starts)) || (cap_records && !d_records)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     *n_records = 0;
     if (!n_reads) {  // an empty piece of a sharded job still exports a (zero) histogram: the exchange is collective
         h->scan_hist_valid = false;
@@ -1387,6 +1399,7 @@ static u64 owner_first_partition(const BriskParams& P, u32 o) { return (((u64)o 
 BRISK_API int brisk_hip_export_hist(brisk_hip_index* h, uint64_t* d_hist_out, uint64_t* partitions_per_owner) {
     if (!h || !d_hist_out || !partitions_per_owner) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
     HIPCHK(h, hipMemcpyAsync(d_hist_out, h->d_hist, h->n_parts * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1397,6 +1410,7 @@ BRISK_API int brisk_hip_export_hist(brisk_hip_index* h, uint64_t* d_hist_out, ui
 BRISK_API int brisk_hip_insert_records_hist(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_hist_slices, uint32_t n_slices) {
     if (!h || (n_records && (!d_records || !d_hist_slices || !n_slices))) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     h->scan_hist_valid = false;
     if (!n_records) return BRISK_HIP_OK;
@@ -1427,6 +1441,7 @@ static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint3
                       uint64_t* counts) {
     if (!h || !counts || (n_records && (!d_records || !d_out))) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     const u32 no = h->P.n_owners;
     for (u32 i = 0; i < no; i++) counts[i] = 0;
     if (!n_records) return BRISK_HIP_OK;
@@ -1463,6 +1478,7 @@ static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint3
 BRISK_API int brisk_hip_insert_records(brisk_hip_index* h, const uint64_t* d_records, uint64_t n_records) {
     if (!h || (n_records && !d_records)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     return insert_records_impl(h, d_records, n_records, false);
 }
@@ -1472,6 +1488,7 @@ BRISK_API int brisk_hip_scan_query(brisk_hip_index* h, const uint32_t* d_packed,
     if (!h || !n_records || (n_reads && (!d_packed || !d_starts)) || (cap_records && (!d_records || !d_tags))) return BRISK_HIP_EINVAL;
     if (n_reads >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 reads in one query batch");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     *n_records = 0;
     if (!n_reads) return BRISK_HIP_OK;
     u64 n = 0, bound = 0;
@@ -1486,6 +1503,7 @@ BRISK_API int brisk_hip_query_records(brisk_hip_index* h, const uint64_t* d_reco
     if (!h || (n_records && (!d_records || !d_sums))) return BRISK_HIP_EINVAL;
     if (n_records >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     if (!n_records) return BRISK_HIP_OK;
     int rc;
     if ((rc = ensure(h, h->tags_a, n_records * 4))) return rc;
@@ -1508,6 +1526,7 @@ BRISK_API int brisk_hip_scan_sequence(brisk_hip_index* h, const char* bases, uin
     const u64 nk = len - h->P.k + 1;
     if (!bases || !skm_ret || !skm_n || !km_lo || !km_hi || !km_idx || cap_kmers < nk) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     const uint64_t offs[2] = {0, len};
     const BriskParams& P = h->P;
     const u32 row = P.w + 1;
@@ -1583,6 +1602,7 @@ BRISK_API int brisk_hip_upsert_kmers(brisk_hip_index* h, const uint64_t* kmer_lo
     for (u64 i = 0; i < n; i++)
         if (minimizer_idx[i] > h->P.w) return fail(h, BRISK_HIP_EINVAL, "minimizer_idx > k-m");
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc;
     if (!h->arena_cap && (rc = ensure_arena(h, 1u << 16))) return rc;
     u64 *d_lo, *d_hi;
@@ -1618,6 +1638,7 @@ BRISK_API int brisk_hip_find_kmers(brisk_hip_index* h, const uint64_t* kmer_lo, 
     if (!h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "not an entry-id index");
     if (!n) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc;
     u64 *d_lo, *d_hi;
     uint8_t *d_idx, *d_new;
@@ -1638,6 +1659,7 @@ BRISK_API int brisk_hip_find_kmers(brisk_hip_index* h, const uint64_t* kmer_lo, 
 BRISK_API int brisk_hip_pack_ascii(brisk_hip_index* h, const char* d_bases, uint64_t n_bases, uint32_t* d_packed) {
     if (!h || (n_bases && (!d_bases || !d_packed))) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     const u64 n_words = (n_bases + 15) / 16;
     if (!n_words) return BRISK_HIP_OK;
     ProfScope ps(h, S_PACK);
@@ -1649,6 +1671,7 @@ BRISK_API int brisk_hip_synth_reads(brisk_hip_index* h, uint64_t genome_len, uin
                                     uint64_t seed_g, uint64_t seed_r, uint32_t* d_packed, uint64_t* d_starts) {
     if (!h || !d_packed || !d_starts || read_len == 0 || genome_len < read_len) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     const u64 n_words = (n_reads * (u64)read_len + 15) / 16;
     const u64 n_threads = std::max<u64>(n_words, n_reads + 1);
     ProfScope ps(h, S_SYNTH);
@@ -1661,6 +1684,7 @@ BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mme
     if (!h || (n && (!mmers || !keys))) return BRISK_HIP_EINVAL;
     if (!n) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc;
     if ((rc = ensure(h, h->lookup_buf, n * 16))) return rc;
     u64* d_x = (u64*)h->lookup_buf.p;
@@ -1690,18 +1714,21 @@ BRISK_API int brisk_hip_debug_phases(uint64_t out[32], int reset) {  // debug bu
 // ---- measurement ---------------------------------------------------------------
 BRISK_API int brisk_hip_profile_enable(brisk_hip_index* h, int on) {
     if (!h) return BRISK_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc = drain_profile(h);
     h->profiling = on != 0;
     return rc;
 }
 BRISK_API int brisk_hip_profile_reset(brisk_hip_index* h) {
     if (!h) return BRISK_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc = drain_profile(h);
     for (int i = 0; i < S_NSLOTS; i++) { h->prof_ms[i] = 0; h->prof_launches[i] = 0; }
     return rc;
 }
 BRISK_API int brisk_hip_profile_read(brisk_hip_index* h, uint32_t* n_slots, const char** names, uint64_t* launches, double* ms) {
     if (!h || !n_slots) return BRISK_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     int rc = drain_profile(h);
     *n_slots = S_NSLOTS;
     for (int i = 0; i < S_NSLOTS; i++) {

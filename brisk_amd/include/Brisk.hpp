@@ -125,6 +125,35 @@ class Brisk {
         enum_pos_++;
         return true;
     }
+    // Every entry once, with its DATA (the BriskWriter's walk, brisk/writer.hpp:99-176: there over the bucket matrix and
+    // the SKLs of every bucket; here over the device's enumeration, buckets ascending).  f(const kmer_full&, const DATA*).
+    template <class F>
+    void visit_entries(F&& f) {
+        std::lock_guard<std::mutex> g(call_mu_);
+        uint64_t cursor = 0, n = 0, cap = 1u << 16;
+        std::vector<uint64_t> lo(cap), hi(cap);
+        std::vector<uint8_t> idx(cap);
+        std::vector<uint32_t> ids(cap);
+        kmer_full km((kint)0, 0, params.m, params.dede);
+        for (;;) {
+            int rc = brisk_hip_enumerate_ids(menu->handle, &cursor, lo.data(), hi.data(), idx.data(), ids.data(), cap, &n);
+            if (rc == BRISK_HIP_ECAPACITY) {  // one bucket range larger than the buffer
+                cap *= 16;
+                lo.resize(cap);
+                hi.resize(cap);
+                idx.resize(cap);
+                ids.resize(cap);
+                continue;
+            }
+            check(rc);
+            if (n == 0) break;
+            for (uint64_t i = 0; i < n; i++) {
+                km.kmer_s = ((kint)hi[i] << 64) | lo[i];
+                km.minimizer_idx = idx[i];
+                f(km, slot(ids[i]));
+            }
+        }
+    }
     void restart_kmer_enumeration() {
         std::lock_guard<std::mutex> g(call_mu_);
         enum_cursor_ = 0;

@@ -55,7 +55,7 @@ class FastaReader {
     bool fill(FastaBatch& out, size_t max_bases) {
         if (out.offs.empty()) out.offs.assign(1, 0);
         const size_t before = out.size();
-        while (out.flat.size() < max_bases) {
+        for (;;) {
             if (pos_ == len_ && !refill()) break;
             // one line (or what the buffer holds of it) per turn: memchr for its end, whole runs of bases appended at once
             const char* p = &buf_[pos_];
@@ -67,6 +67,11 @@ class FastaReader {
                     in_header_ = true;
                 }
             }
+            // A full batch ends where no sequence is running -- in front of the next record's header, or behind a
+            // character that cut the sequence.  (Checked here, after the header of the next record has closed the run:
+            // with one sequence line per record, as in a file of reads, the run is open at the end of EVERY line, and a
+            // check at the end of the line would never let a batch end before the end of the file.)
+            if (out.flat.size() >= max_bases && out.flat.size() == out.offs.back()) break;
             const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
             const char* stop = nl ? nl : end;
             if (!in_header_) append_bases(out, p, stop);

@@ -6,8 +6,21 @@
  * between that host-side C++ (brisk_amd/include/Brisk.hpp, same names as the
  * reference's) and the HIP kernels.  Plain pointers and sizes only; no C++,
  * torch or HIP types appear in any signature.  Every entry point returns an
- * int status (BRISK_HIP_OK == 0), never throws, and is thread-compatible: one
- * HIP stream per handle, external synchronisation between threads.
+ * int status (BRISK_HIP_OK == 0) and never throws.
+ *
+ * Threads.  The reference lets any number of OpenMP threads call insert_superkmer /
+ * get_superkmer at once under its lock stripes (brisk/Brisk.hpp:112-114,140-143,
+ * brisk/DenseMenuYo.hpp:110-118; apps/counter.cpp:197-227,314-346).  Here the unit of
+ * work is a batch, and a handle takes ONE call at a time (a per-handle lock inside the
+ * library; one HIP stream per handle): any number of host threads may call any entry
+ * points on one handle concurrently -- e.g. one thread streaming brisk_hip_insert_reads
+ * batches while another issues brisk_hip_get_reads / brisk_hip_lookup -- and every call
+ * runs against the index as left by a whole number of the other threads' completed
+ * calls.  A concurrent get therefore observes whole batches only: never a partly
+ * inserted batch, never a torn entry (a key without its count, a count updated for some
+ * of a read's k-mers only).  Which batches it observes depends on timing, as in the
+ * reference.  Calls on different handles are independent.  brisk_hip_last_error is the
+ * one exception: it returns the handle's last message without taking the lock.
  *
  * Reference interface each entry point stands in for (file:line under the
  * reference tree):

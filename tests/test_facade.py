@@ -126,3 +126,41 @@ def test_two_rank_rehearsal_matches_single_rank():
     assert d2["n_gpus"] == 2 and v2["every_kmer_counted_once"]
     for key in ("entries", "nb_kmers", "nb_buckets", "sum_counts", "digest_mod_2_64"):
         assert v1[key] == v2[key], key
+
+
+@pytest.mark.gpu
+def test_strong_scaling_rehearsal_three_ranks_odd_reads():
+    """bench.py --scaling strong: the job is fixed (--reads in all), rank r takes its contiguous share; three gloo ranks on
+    one GPU with a read count that does not divide build the same index as one rank, and the line says "strong"."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    reads = "500001"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", reads, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--scaling", "strong"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port",
+                            str(29950 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--backend", "gloo", "--share-gpu", "--reads", reads,
+                            "--scaling", "strong", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert three.returncode == 0, three.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    d3 = json.loads([l for l in three.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["scaling"] == d3["scaling"] == "strong" and d3["n_gpus"] == 3 and d3["config"]["total_reads"] == int(reads)
+    assert d3["verify"]["every_kmer_counted_once"]
+    for key in ("entries", "nb_kmers", "nb_buckets", "sum_counts", "digest_mod_2_64"):
+        assert d1["verify"][key] == d3["verify"][key], key
+
+
+@pytest.mark.gpu
+def test_sharded_count_with_unequal_and_empty_shares():
+    """ranks holding different numbers of reads -- on different sides of the piece thresholds, one of them
+    none at all -- must issue the same collectives.  Two gloo ranks on one GPU count two batches (the second one with
+    an empty rank and a different piece count than the first); the shards' digests add up to the single-index digest."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(30300 + os.getpid() % 300), os.path.join(ROOT, "tests", "uneven_ranks_worker.py")], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["pieces"] == [2, 4], d
+    assert d["sharded"] == d["single"], d

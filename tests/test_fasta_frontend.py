@@ -82,3 +82,25 @@ def test_plain_files_are_parsed_by_several_threads(dumper, tmp_path):
     for batch in (200, 7000, 1 << 20):
         for threads in (1, 2, 5, 8):
             assert run(dumper, p, batch, threads) == want, (batch, threads)
+
+
+def test_batches_of_one_line_records_end_between_records(dumper, tmp_path):
+    """A file of reads has ONE sequence line per record: the running sequence is open at the end of every line, and a
+    batch must still end in front of the next record's header once it is full -- not at the end of the file (a 5 M-read
+    .fa.gz used to arrive as one batch).  gz (streamed) and plain (mapped) paths."""
+    rng = random.Random(9)
+    reads = ["".join(rng.choice("ACGT") for _ in range(150)) for _ in range(400)]
+    text = "".join(">\n%s\n" % r for r in reads)
+    gz = str(tmp_path / "reads.fa.gz")
+    with gzip.open(gz, "wt") as f:
+        f.write(text)
+    plain = str(tmp_path / "reads.fa")
+    open(plain, "w").write(text)
+    for path in (gz, plain):
+        out = subprocess.run([dumper, path, "3000", "0", "marks"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        lines = [l for l in out.stdout.split("\n") if l]
+        sizes = [int(l.split()[1]) for l in lines if l.startswith("#batch")]
+        assert [l for l in lines if not l.startswith("#")] == reads
+        assert sum(sizes) == len(reads) and len(sizes) >= 15, sizes  # 60 kb in batches of >= 3 kb: 20 whole reads each
+        assert max(sizes) <= 40, sizes
