@@ -69,20 +69,23 @@ static int run_mixed(const char* path, uint8_t k, uint8_t m, uint8_t b, const do
         std::lock_guard<std::mutex> g(mu);
         log.push_back(line);
     };
-    std::thread getter([&]() {
-        size_t last = (size_t)-1;
-        while (!done && !failed) {
+    std::thread getter([&]() {  // keeps asking about batches that are in -- the newest one first, then all of them in turn
+        size_t newest_asked = (size_t)-1, turn = 0, asked = 0;
+        const size_t max_gets = getenv("BRISK_MIXED_MAX_GETS") ? (size_t)atoll(getenv("BRISK_MIXED_MAX_GETS")) : 2000;
+        while (!done && !failed && asked < max_gets) {
             size_t have;
             {
                 std::lock_guard<std::mutex> g(mu);
                 have = samples.size();
             }
-            if (have == 0 || have - 1 == last) {
+            if (have == 0) {
                 std::this_thread::yield();
                 continue;
             }
-            last = have - 1;
-            query(last, "get");
+            size_t which = turn++ % have;
+            if (have - 1 != newest_asked) which = newest_asked = have - 1;
+            query(which, "get");
+            asked++;
         }
     });
     FastaBatcher batches(path, batch_bases);

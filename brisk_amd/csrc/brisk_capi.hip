@@ -5,6 +5,7 @@
 #include "brisk_kernels.hip"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -110,6 +111,8 @@ int fail(brisk_hip_index* h, int code, const std::string& msg) {
     return code;
 }
 
+bool pool_drain();
+
 int ensure(brisk_hip_index* h, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes) return BRISK_HIP_OK;
     if (b.p) {
@@ -120,6 +123,10 @@ int ensure(brisk_hip_index* h, DevBuf& b, size_t bytes) {
     }
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&b.p, want);
+    if (e == hipErrorOutOfMemory && pool_drain()) {  // the arenas of destroyed indexes may be what is in the way
+        (void)hipGetLastError();
+        e = hipMalloc(&b.p, want);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();  // the failed allocation must not surface later as some kernel's launch error
         b.p = nullptr;
@@ -194,6 +201,10 @@ int vm_grow(brisk_hip_index* h, VmBuf& b, size_t bytes) {
         if (b.mapped + add > b.reserved) return fail(h, BRISK_HIP_ENOMEM, "arena: virtual reservation exhausted");
         hipMemGenericAllocationHandle_t hd;
         hipError_t e = hipMemCreate(&hd, add, &prop, 0);
+        if (e != hipSuccess && pool_drain()) {  // the arenas of destroyed indexes may be what is in the way
+            (void)hipGetLastError();
+            e = hipMemCreate(&hd, add, &prop, 0);
+        }
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return fail(h, BRISK_HIP_ENOMEM, std::string("arena growth: hipMemCreate: ") + hipGetErrorString(e));
@@ -233,14 +244,23 @@ void vm_free(VmBuf& b) {  // a reservation nothing was ever mapped into may go b
     b = VmBuf{};
 }
 
-// A virtual address that has been unmapped must never be mapped again in this process: on this stack
-// (ROCm 7.2, gfx950) a kernel touching memory freshly mapped at a previously unmapped address now and
-// then takes a memory access fault (seen with hipMemUnmap + hipMemMap at the same offset, and with
-// hipMemAddressFree + hipMemAddressReserve handing the same range out again).  So:
-//  * arenas of destroyed indexes go to a small pool WITH their mappings and are handed to the next
-//    index on the same device (also saves reserve/map/unmap per index);
-//  * an arena that is not pooled is retired: its physical memory is released, its virtual range stays
-//    reserved for the life of the process (address space only) so that nothing is mapped there again.
+// A virtual address that has been unmapped must never be mapped again in this process.  What was seen (ROCm 7.2, gfx950,
+// BRISK_DEBUG_VMM=1, round 1's gpurun_out/fs.log; never reproduced in isolation, so the cause below is an attribution):
+//   counts arena, reservation 0x74eca7000000 + 17 GiB:  hipMemCreate/hipMemMap 1 GiB at base; + 1 GiB at 0x74ece7000000;
+//   the index is destroyed and its arena trimmed: hipMemUnmap(0x74ece7000000, 1 GiB) + hipMemRelease;
+//   the next index grows: hipMemCreate(6 GiB) + hipMemMap(0x74ece7000000, 6 GiB) + hipMemSetAccess(base, 7 GiB)
+//   (always from the base: this stack answers "invalid argument" to hipMemSetAccess on some sub-ranges that start past
+//   earlier mappings); k_insert then stores counts at 0x74ed00008000 -- 400 MiB into the re-mapped piece, inside the range
+//   that had been mapped and unmapped before -- and the GPU reports a memory access fault at exactly that address.
+// The same was seen with hipMemAddressFree + hipMemAddressReserve handing the same range out again.  Consistent with a
+// translation for the unmapped range surviving the unmap; nothing in this library touches the range in between.  So:
+//  * arenas of destroyed indexes go to a small pool WITH their mappings and are handed to the next index on the same
+//    device, whatever their size (a bench-size arena -- 100 GB mapped -- is reused, not retired); the pool gives its
+//    physical memory back when an allocation of this library fails for lack of memory (pool_drain), so what it holds
+//    is never what makes a new index fail;
+//  * an arena that is not pooled (pool full: the smallest one goes) is retired: its physical memory is released, its
+//    virtual range stays reserved for the life of the process (address space only; g_retired_va counts it,
+//    brisk_hip_memory_info reports it) so that nothing is mapped there again.
 struct VmSet {
     int device = -1;
     VmBuf keys, counts, ids;
@@ -249,7 +269,7 @@ struct VmSet {
 std::mutex g_pool_mu;
 std::vector<VmSet> g_pool;
 constexpr size_t kPoolMaxArenas = 4;
-constexpr size_t kPoolMaxBytes = (size_t)40 << 30;  // physical memory the pool may hold
+std::atomic<unsigned long long> g_retired_va{0};  // bytes of address space retired arenas keep reserved
 
 void vm_retire(VmBuf& b) {  // give the physical memory back, keep the address range out of circulation
     size_t off = 0;
@@ -258,6 +278,7 @@ void vm_retire(VmBuf& b) {  // give the physical memory back, keep the address r
         hipMemRelease(b.handles[i]);
         off += b.sizes[i];
     }
+    if (b.base) g_retired_va += b.reserved;
     b = VmBuf{};
 }
 bool pool_take(int device, bool want_ids, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
@@ -275,10 +296,7 @@ bool pool_take(int device, bool want_ids, VmBuf& keys, VmBuf& counts, VmBuf& ids
 }
 void pool_give(int device, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    size_t held = 0;
-    for (const VmSet& s : g_pool) held += s.mapped();
-    const size_t mine = keys.mapped + counts.mapped + ids.mapped;
-    if (!keys.base || !counts.base || g_pool.size() >= kPoolMaxArenas || held + mine > kPoolMaxBytes) {
+    if (!keys.base || !counts.base) {
         vm_retire(keys);
         vm_retire(counts);
         vm_retire(ids);
@@ -291,6 +309,34 @@ void pool_give(int device, VmBuf& keys, VmBuf& counts, VmBuf& ids) {
     s.ids = ids;
     g_pool.push_back(s);
     keys = counts = ids = VmBuf{};
+    while (g_pool.size() > kPoolMaxArenas) {  // full: the arena with the least memory behind it is the cheapest to lose
+        size_t least = 0;
+        for (size_t i = 1; i < g_pool.size(); i++)
+            if (g_pool[i].mapped() < g_pool[least].mapped()) least = i;
+        vm_retire(g_pool[least].keys);
+        vm_retire(g_pool[least].counts);
+        vm_retire(g_pool[least].ids);
+        g_pool.erase(g_pool.begin() + least);
+    }
+}
+// an allocation failed for lack of device memory: give back what the pool holds; true if that freed anything
+bool pool_drain() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    bool any = false;
+    for (VmSet& s : g_pool) {
+        any = any || s.mapped() > 0;
+        vm_retire(s.keys);
+        vm_retire(s.counts);
+        vm_retire(s.ids);
+    }
+    g_pool.clear();
+    return any;
+}
+size_t pool_bytes() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t held = 0;
+    for (const VmSet& s : g_pool) held += s.mapped();
+    return held;
 }
 
 // arena growth.  With virtual memory management: map more physical memory behind the reserved
@@ -1080,6 +1126,9 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
                     vm_free(h->vm_counts);
                     vm_free(h->vm_ids);
                     h->err.clear();
+                    fprintf(stderr, "[brisk_hip] create: no virtual range of %llu GiB for the arena (%llu GiB of address space are held by retired arenas): "
+                                    "falling back to copy-on-growth allocations\n",
+                            (unsigned long long)(max_entries * 17 >> 30), (unsigned long long)(g_retired_va.load() >> 30));
                 }
             }
         }
@@ -1326,6 +1375,16 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
             m += b->bytes;
         *memory_bytes = m;
     }
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_memory_info(brisk_hip_index* h, uint64_t out[4]) {
+    if (!h || !out) return BRISK_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    out[0] = h->use_vmm ? h->vm_keys.mapped + h->vm_counts.mapped + h->vm_ids.mapped : h->arena_cap * (h->entry_ids ? 21 : 17);
+    out[1] = h->use_vmm ? h->vm_keys.reserved + h->vm_counts.reserved + h->vm_ids.reserved : 0;
+    out[2] = pool_bytes();
+    out[3] = g_retired_va.load();
     return BRISK_HIP_OK;
 }
 

@@ -78,7 +78,7 @@
 extern "C" {
 #endif
 
-#define BRISK_HIP_ABI_VERSION 2
+#define BRISK_HIP_ABI_VERSION 3
 
 enum {
     BRISK_HIP_OK = 0,
@@ -167,6 +167,13 @@ int brisk_hip_enumerate(brisk_hip_index *h, uint64_t *cursor, uint64_t *out_lo, 
  * here as: super-k-mer records received, largest partition (entries). */
 int brisk_hip_stats(brisk_hip_index *h, uint64_t *nb_buckets, uint64_t *nb_skmers, uint64_t *nb_kmers,
                     uint64_t *memory_bytes, uint64_t *largest_bucket);
+
+/* Where the arena's memory is (no reference counterpart; Brisk::stats reports the process' peak RSS, brisk/Brisk.hpp:184-189):
+ * out[0] = device memory mapped behind this index's arena, out[1] = virtual address range this index has reserved for it
+ * (0 without virtual memory management), out[2] = device memory held, process-wide, by the pooled arenas of destroyed
+ * indexes (handed to the next index, given back when an allocation fails for lack of memory), out[3] = address space,
+ * process-wide, that retired arenas keep reserved for the life of the process (no memory behind it). */
+int brisk_hip_memory_info(brisk_hip_index *h, uint64_t out[4]);
 
 /* Order-independent digest of the whole index, for parity checks at sizes where the multiset
  * cannot be compared line by line: out[0] = number of entries, out[1] = sum of counts,

