@@ -155,7 +155,11 @@ int main(int argc, char** argv) {
                     en.next(v);
                 }
             }
-            kmer_full km((kint)0, 0, m, params.dede);
+            if (getenv("BRISK_REALLOCATE")) {  // Brisk::reallocate (brisk/Brisk.hpp:202-224): the same entries under (k, m + 2, b + 2)
+                index.reallocate();
+                std::cout << "reallocated k " << (int)index.params.k << " m " << (int)index.params.m << " b " << (int)index.params.b << std::endl;
+            }
+            kmer_full km((kint)0, 0, index.params.m, index.params.dede);
             bool first_entry = true;
             while (index.next(km)) {
                 uint8_t* c = index.get(km);

@@ -1378,6 +1378,76 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     return BRISK_HIP_OK;
 }
 
+// Brisk::reallocate (brisk/Brisk.hpp:202-224): every entry of `from` is moved into `to`, an empty index over the same k with
+// its own (m, b) -- the reference re-buckets to (m + 2, b + 2).  The reference's loop calls a four-argument update_kmer that
+// no file defines (the member template is never instantiated, its call site is commented out, brisk/Brisk.hpp:124-129), so
+// what "the k-mer under the new m" means is taken from the path itself: the (kmer_s, minimizer_idx) that
+// SuperKmerEnumerator yields for the k-mer as a sequence of k nts at the new m -- what would be there had the index been
+// built at the new parameters.  On the device: entries -> reads of k nts -> the scan at the new parameters (one record
+// of one k-mer per read) -> each record takes its entry's count as its multiplicity -> the insert.  Entries of `from`
+// that the new minimizer maps to one identity (the same canonical k-mer stored under several identities)
+// merge, their counts added mod 256.  `from` is left untouched.
+BRISK_API int brisk_hip_reallocate(brisk_hip_index* from, brisk_hip_index* to) {
+    if (!from || !to || from == to) return BRISK_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> lock_from(from->call_mu);
+    std::lock_guard<std::recursive_mutex> call_lock(to->call_mu);
+    brisk_hip_index* h = to;
+    if (from->P.k != to->P.k || from->device != to->device) return fail(h, BRISK_HIP_EINVAL, "reallocate: both indexes must have the same k and device");
+    if (from->entry_ids || to->entry_ids) return fail(h, BRISK_HIP_EINVAL, "reallocate: entry-id indexes are re-bucketed by the facade (DATA lives on the host)");
+    if (to->P.n_owners > 1 || from->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "reallocate on a sharded index");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(from->stream));
+    const u32 k = from->P.k;
+    // the old index's partition sizes
+    std::vector<u32> cnt(from->n_parts);
+    hipLaunchKernelGGL(k_dir_counts, dim3(nblocks(from->n_parts, 256)), dim3(256), 0, h->stream, from->ix.dir, from->n_parts, from->d_cur32);
+    if (int lrc = launch_check(h, "k_dir_counts")) return lrc;
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), from->d_cur32, from->n_parts * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const u64 round_cap = 1ull << 24;  // entries per round
+    std::vector<u64> base;
+    for (u64 p = 0; p < from->n_parts;) {
+        while (p < from->n_parts && cnt[p] == 0) p++;
+        if (p >= from->n_parts) break;
+        base.clear();
+        u64 total = 0, q = p;
+        while (q < from->n_parts && (total == 0 || total + cnt[q] <= round_cap)) {
+            base.push_back(total);
+            total += cnt[q];
+            q++;
+        }
+        const u64 np = q - p, n_words = (total * k + 15) / 16;
+        int rc;
+        if ((rc = ensure(h, h->enum_out, np * 8 + total * 22 + 64))) return rc;
+        if ((rc = ensure(h, h->packed_tmp, (n_words + 4) * 4))) return rc;
+        if ((rc = ensure(h, h->starts_tmp, (total + 1) * 8))) return rc;
+        char* b0 = (char*)h->enum_out.p;
+        u64* d_base = (u64*)b0;
+        u64* d_lo = (u64*)(b0 + np * 8);
+        u64* d_hi = d_lo + total;
+        uint8_t* d_idx = (uint8_t*)(d_hi + total) + total * 4;
+        uint8_t* d_cnt = d_idx + total;
+        HIPCHK(h, hipMemcpyAsync(d_base, base.data(), np * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_enumerate, dim3((u32)np), dim3(64), 0, h->stream, from->P, from->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt, (u32*)nullptr);
+        if ((rc = launch_check(h, "k_enumerate"))) return rc;
+        HIPCHK(h, hipMemsetAsync((char*)h->packed_tmp.p + n_words * 4, 0, 16, h->stream));
+        hipLaunchKernelGGL(k_kmers_to_reads, dim3(nblocks(std::max<u64>(n_words, total + 1), 256)), dim3(256), 0, h->stream, d_lo, d_hi, total, k, (u32*)h->packed_tmp.p,
+                           n_words, (u64*)h->starts_tmp.p);
+        if ((rc = launch_check(h, "k_kmers_to_reads"))) return rc;
+        // the scan as the query path runs it: its records carry the index of the read they came from (one record per read here)
+        u64 n_rec = 0;
+        bool hist_ok = true;
+        if ((rc = scan_to_staging(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, total, true, true, &n_rec, &hist_ok))) return rc;
+        if (n_rec != total) return fail(h, BRISK_HIP_EHIP, "reallocate: " + std::to_string(total) + " k-mers gave " + std::to_string(n_rec) + " records");
+        hipLaunchKernelGGL(k_set_multiplicity, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, (u64*)h->staging.p, n_rec, h->P.stride, (const u32*)h->tags_a.p, d_cnt);
+        if ((rc = launch_check(h, "k_set_multiplicity"))) return rc;
+        if ((rc = insert_records_impl(h, (const u64*)h->staging.p, n_rec, hist_ok))) return rc;
+        p = q;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return check_device_flags(h);
+}
+
 BRISK_API int brisk_hip_memory_info(brisk_hip_index* h, uint64_t out[4]) {
     if (!h || !out) return BRISK_HIP_EINVAL;
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);

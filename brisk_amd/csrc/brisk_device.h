@@ -28,7 +28,8 @@ struct BriskParams {
 };
 
 // record header word: [0,32) routing id, [32,40) n k-mers, [40,48) idx' of k-mer 0,
-// [48,64) zero (k_insert_big keeps a collapsed record's multiplicity in [48,56) inside its own copy of the records).
+// [48,56) multiplicity and bit 56 "has a multiplicity" (zero as the scan emits records: one vector each; k_insert_big sets
+// them on records it has collapsed, brisk_hip_reallocate on the one-k-mer records that carry an entry's count), rest zero.
 // idx' = minimizer_idx + suff_reduc (SuperKmerLight.hpp:98).
 // Routing id = the bucket id (Brisk.hpp:135-137) followed by ext_bits more bits of the same hashed minimizer:
 // every k-mer of a super-k-mer shares them, so records can be spread over up to 2^24 partitions however small b is

@@ -330,6 +330,7 @@ __device__ __forceinline__ void expand_and_dedupe_words(u32 lane, u32 ninst, u32
 // later copy.  Header bits 48..55 carry a record's multiplicity (mod 256: counts wrap there anyway) once a partition's
 // records have been collapsed; they are not part of its identity.
 #define HDR_ID_MASK 0x0000ffffffffffffull
+#define HDR_HAS_MULT (1ull << 56)   // header bits 48..55 hold the record's multiplicity (mod 256, as the counts are)
 __device__ __forceinline__ bool dedupe_records(u32 stride, const RecRegs& rr, u32 my_mult, u32 nrec, u32 lane, const u64* s_rec, u32* s_rtab, u32* s_rmult) {
     s_rtab[lane] = EMPTY_SLOT;
     s_rtab[lane + 64] = EMPTY_SLOT;
@@ -479,7 +480,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
                     const unsigned long long bal = __ballot(keep);
                     if (keep) {  // survivors move to the front of the partition's records (never past what is still to be read)
                         u64* dst = rec + (u64)(wr + (u32)__popcll(bal & lanes_below(lane))) * P.stride;
-                        const u64 mult = (u64)(s_rmult[lane] & 0xffu) << 48;
+                        const u64 mult = ((u64)(s_rmult[lane] & 0xffu) << 48) | HDR_HAS_MULT;
                         dst[0] = rr.w0;
                         dst[1] = P.stride == 2 ? rr.w1 | mult : rr.w1;
                         if (P.stride > 2) dst[2] = P.stride == 3 ? rr.w2 | mult : rr.w2;
@@ -511,7 +512,9 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
                 }
                 const u64 my_hdr = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
                 const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
-                const u32 my_mult = collapsed ? (u32)(my_hdr >> 48) & 0xffu : 1u;
+                // a record stands for one vector, unless its header says how many (collapsed records above; the entries of
+                // an index being re-bucketed, brisk_hip_reallocate: one k-mer with its count)
+                const u32 my_mult = (my_hdr & HDR_HAS_MULT) ? (u32)(my_hdr >> 48) & 0xffu : 1u;
                 const u32 x0 = wave_incl_scan(raw_n, lane);
                 // First try every available record: identical records (the same super-k-mer seen in
                 // several reads) collapse into one with a multiplicity, so far more raw instances fit.

@@ -308,3 +308,31 @@ __global__ void __launch_bounds__(64) k_expand_records(BriskParams P, const u64*
     out_hi[(u64)r * row + lane] = hk.hi;
     out_idx[(u64)r * row + lane] = (uint8_t)idx;
 }
+
+// ---- re-bucketing (Brisk::reallocate, brisk/Brisk.hpp:202-224): the entries of an index become reads of exactly k nts ----
+// one thread per word (16 nts) of the packed stream of n k-mers laid end to end: k-mer e = nts [e*k, (e+1)*k)
+__global__ void __launch_bounds__(256) k_kmers_to_reads(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 n, u32 k, u32* __restrict__ packed, u64 n_words,
+                                                        u64* __restrict__ starts) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w <= n) starts[w] = w * (u64)k;
+    if (w >= n_words) return;
+    const u64 total = n * (u64)k;
+    u32 v = 0;
+    for (int i = 0; i < 16; i++) {
+        const u64 q = w * 16 + i;
+        u32 c = 0;
+        if (q < total) {
+            const u64 e = q / k;
+            const u32 j = (u32)(q - e * k);  // nt j of the k-mer, from its left end: bits [2(k-1-j), 2(k-j))
+            c = (u32)shr128(mk128(lo[e], hi[e]), 2 * (k - 1 - j)).lo & 3u;
+        }
+        v = (v << 2) | c;
+    }
+    packed[w] = v;
+}
+// every record of a re-bucketing scan holds one k-mer: it carries the count of the entry it came from as its multiplicity
+__global__ void __launch_bounds__(256) k_set_multiplicity(u64* __restrict__ rec, u64 n_rec, u32 stride, const u32* __restrict__ tags, const uint8_t* __restrict__ cnt) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    rec[i * stride + stride - 1] |= HDR_HAS_MULT | ((u64)cnt[tags[i]] << 48);
+}

@@ -101,7 +101,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
-    "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
+    "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_reallocate", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
     "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
@@ -135,6 +135,7 @@ def load() -> C.CDLL:
     L.brisk_hip_stats.argtypes = [vp] + [C.POINTER(u64)] * 5
     L.brisk_hip_checksum.argtypes = [vp, _u64p]
     L.brisk_hip_memory_info.argtypes = [vp, _u64p]
+    L.brisk_hip_reallocate.argtypes = [vp, vp]
     L.brisk_hip_scan_packed.argtypes = [vp, vp, vp, u64, vp, u64, C.POINTER(u64)]
     L.brisk_hip_scan_bound.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.brisk_hip_route_records.argtypes = [vp, vp, u64, vp, _u64p]
@@ -284,6 +285,12 @@ class BriskHip:
         v = [C.c_uint64() for _ in range(5)]
         self._chk(self.L.brisk_hip_stats(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("nb_buckets", "nb_skmers", "nb_kmers", "memory_bytes", "largest_bucket"), (x.value for x in v)))
+
+    def reallocate_into(self, fresh: "BriskHip") -> None:
+        """Brisk::reallocate: move every entry into `fresh`, an empty index over the same k with its own (m, b)."""
+        rc = self.L.brisk_hip_reallocate(self.h, fresh.h)
+        if rc:
+            raise BriskHipError(rc, self.L.brisk_hip_last_error(fresh.h).decode())
 
     def memory_info(self) -> dict:
         out = np.zeros(4, np.uint64)

@@ -172,9 +172,53 @@ class Brisk {
         struct rusage usage;
         return getrusage(RUSAGE_SELF, &usage) == 0 ? (uint64_t)usage.ru_maxrss : 0;
     }
-    // brisk/Brisk.hpp:202-224 re-buckets to (m+2, b+2); its only call site is commented out there
-    // (:124-129).  Not built: SURVEY.md 8(f)-3.
-    void reallocate() {}
+    // brisk/Brisk.hpp:202-224: the index re-bucketed to (m + 2, b + 2); the reference's only call site is commented out
+    // (:124-129) and its loop calls an update_kmer overload that no file defines, so "the k-mer under the new m" is
+    // taken from the path itself: what SuperKmerEnumerator yields for the k-mer as a sequence of k nts at the new m
+    // (include/brisk_hip.h, brisk_hip_reallocate, does the same on the device for bulk-count indexes).  DATA lives on
+    // the host here, so the walk is the reference's: every entry, in turn, into the new index, its DATA copied over
+    // (`*value = *old_value`, :217; entries that merge keep the DATA of the last one, as that line does).  One launch
+    // per k-mer: the per-call API's cost, on a path the reference never runs.  Throws std::invalid_argument when
+    // (k, m + 2, b + 2) is not a valid triple (m + 2 >= k).
+    void reallocate() {
+        Parameters grown(params.k, (uint8_t)(params.m + 2), (uint8_t)(params.b + 2));
+        std::unique_ptr<DenseMenuYo<DATA>> big(new DenseMenuYo<DATA>(grown));
+        struct Old {
+            kint kmer_s;
+            const DATA* data;
+        };
+        std::vector<Old> old;
+        visit_entries([&](const kmer_full& km, const DATA* d) { old.push_back(Old{km.kmer_s, d}); });
+        std::lock_guard<std::mutex> g(call_mu_);
+        std::vector<std::unique_ptr<DATA[]>> fresh_chunks;
+        auto fresh_slot = [&](uint32_t id) -> DATA* {
+            const size_t c = id >> 16;
+            while (fresh_chunks.size() <= c) fresh_chunks.emplace_back(new DATA[1u << 16]);
+            return &fresh_chunks[c][id & 0xffff];
+        };
+        std::vector<kmer_full> v;
+        for (const Old& o : old) {
+            std::string s = kmer2str(o.kmer_s, params.k);
+            SuperKmerEnumerator en(s, grown.k, grown.m, grown.dede);
+            v.clear();
+            en.next(v);  // a sequence of k nts: one vector of one k-mer
+            if (v.size() != 1) throw std::runtime_error("Brisk::reallocate: a k-mer did not come back as one k-mer");
+            const uint64_t lo = (uint64_t)v[0].kmer_s, hi = (uint64_t)(v[0].kmer_s >> 64);
+            uint32_t id = 0;
+            uint8_t is_new = 0;
+            if (brisk_hip_upsert_kmers(big->handle, &lo, &hi, &v[0].minimizer_idx, 1, &id, &is_new) != BRISK_HIP_OK)
+                throw std::runtime_error(std::string("brisk_hip: ") + brisk_hip_last_error(big->handle));
+            *fresh_slot(id) = *o.data;
+        }
+        delete menu;
+        menu = big.release();
+        params = grown;
+        chunks_ = std::move(fresh_chunks);
+        enum_cursor_ = 0;
+        enum_pos_ = 0;
+        e_lo_.clear();
+        e_hi_.clear();
+    }
 
   private:
     void check(int rc) const {

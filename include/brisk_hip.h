@@ -31,6 +31,7 @@
  *   brisk_hip_clear             `delete menu; menu = new DenseMenuYo` (what Brisk::reallocate does
  *                               to start over, brisk/Brisk.hpp:220-222): an empty index that keeps
  *                               its device memory reserved
+ *   brisk_hip_reallocate        Brisk::reallocate (brisk/Brisk.hpp:202-224)
  *   brisk_hip_insert_reads      count_sequence loop: SuperKmerEnumerator::next +
  *                               Brisk::protect_data/insert_superkmer/unprotect_data +
  *                               the counter update (apps/counter.cpp:231-276,
@@ -167,6 +168,12 @@ int brisk_hip_enumerate(brisk_hip_index *h, uint64_t *cursor, uint64_t *out_lo, 
  * here as: super-k-mer records received, largest partition (entries). */
 int brisk_hip_stats(brisk_hip_index *h, uint64_t *nb_buckets, uint64_t *nb_skmers, uint64_t *nb_kmers,
                     uint64_t *memory_bytes, uint64_t *largest_bucket);
+
+/* Brisk::reallocate (brisk/Brisk.hpp:202-224: the index re-bucketed to (m + 2, b + 2); dormant in the reference): every
+ * entry of `from` goes into `to` -- an EMPTY bulk-count index over the same k and device, created by the caller with the
+ * new (m, b) -- under the identity (kmer_s, minimizer_idx) that SuperKmerEnumerator gives the k-mer at the new m, with
+ * its count; entries that the new minimizer maps to one identity merge, counts added mod 256.  `from` stays as it is. */
+int brisk_hip_reallocate(brisk_hip_index *from, brisk_hip_index *to);
 
 /* Where the arena's memory is (no reference counterpart; Brisk::stats reports the process' peak RSS, brisk/Brisk.hpp:184-189):
  * out[0] = device memory mapped behind this index's arena, out[1] = virtual address range this index has reserved for it
