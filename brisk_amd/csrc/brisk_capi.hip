@@ -1495,18 +1495,17 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     *n_records = 0;
     if (!n_reads) {  // an empty piece of a sharded job still exports a (zero) histogram: the exchange is collective
         h->scan_hist_valid = false;
-        if (h->P.n_owners > 1) {
-            HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
-            h->scan_hist_valid = true;
-        }
+        HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+        h->scan_hist_valid = true;
         return BRISK_HIP_OK;
     }
     u64 n = 0;
     u64 bound = 0;
     int rc = count_kmers(h, d_starts, n_reads, &bound);
     if (rc) return rc;
-    // a sharded index keeps the per-partition histogram of what it scanned: the owners need it (export_hist)
-    const bool want_hist = h->P.n_owners > 1;
+    // the per-partition histogram of what was scanned is kept: the owners of a sharded job need it (export_hist), also
+    // when the job happens to have one owner
+    const bool want_hist = true;
     bool hist_ok = false;
     h->scan_hist_valid = false;
     rc = scan_impl(h, d_packed, d_starts, n_reads, d_records, cap_records, want_hist, false, nullptr, &n, nullptr, bound, &hist_ok);

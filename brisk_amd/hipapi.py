@@ -59,6 +59,14 @@ def build_apps(verbose: bool = False) -> dict:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     out["brisk_count"] = os.path.join(apps, "brisk_count")
+    # the multi-GPU job from C++: one process per GPU, RCCL grouped send/recv (apps/brisk_shard.cpp)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-std=gnu++17", "-O2", "-pthread", "-D__HIP_PLATFORM_AMD__"] + inc + ["-I" + os.path.join(rocm, "include"), os.path.join(apps, "brisk_shard.cpp")] + link + \
+          ["-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", os.path.join(apps, "brisk_shard")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    out["brisk_shard"] = os.path.join(apps, "brisk_shard")
     ref_counter = "/root/reference/apps/counter.cpp"
     if os.path.exists(ref_counter):
         cmd = ["g++", "-std=gnu++17", "-O2", "-w", "-include", "cstdint", "-fopenmp"] + inc + ["-I/root/reference/apps", ref_counter] + link + \
