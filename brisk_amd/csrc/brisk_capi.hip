@@ -76,6 +76,7 @@ struct brisk_hip_index {
     IndexDev ix{};
     // scratch
     DevBuf route_buf;
+    DevBuf bins;  // binned layout: n_parts bins of bin_cap records
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
@@ -395,18 +396,26 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
 }
 
 // exclusive prefix of the record histogram -> d_off (n_parts+1), d_cur32 seeded
-int prefix_partitions(brisk_hip_index* h, u64 n_bins) {
+int prefix_partitions(brisk_hip_index* h, u64 n_bins, u32 sub = 0) {  // sub: over the records beyond `sub` per partition
     ProfScope ps(h, S_PSUM);
     const u32 nb = nblocks(n_bins, 256 * SCAN_ITEMS);
-    hipLaunchKernelGGL(k_psum_block, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums);
+    hipLaunchKernelGGL(k_psum_block, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums, sub);
     hipLaunchKernelGGL(k_psum_top, dim3(1), dim3(1024), 0, h->stream, h->d_block_sums, nb);
-    hipLaunchKernelGGL(k_psum_apply, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums, h->d_off, h->d_cur32);
+    hipLaunchKernelGGL(k_psum_apply, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums, h->d_off, h->d_cur32, sub);
     return launch_check(h, "prefix_partitions");
 }
 
 // records (unordered, all owned by this index) -> index.  If have_hist, d_hist
 // already holds this batch's per-partition histogram (the scan filled it).
-int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist);
+// `bl` (binned layout): the scan wrote the records into per-partition bins (bl->bins, bin_cap records each) and the
+// n_ovf records beyond them into bl->ovf; d_hist holds the histogram.  Null: d_rec holds the records, in any order.
+struct BinLayout {
+    u64* bins;
+    u32 bin_cap;
+    u64* ovf;
+    u64 n_ovf;
+};
+int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist, const BinLayout* bl = nullptr);
 
 // Records in any split are still a valid batch: when the single-pass arena reserve for a batch does not
 // fit the device (BRISK_HIP_ENOMEM is raised before anything is written), insert it as two halves.
@@ -418,7 +427,7 @@ int insert_records_impl(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     return insert_records_impl(h, d_rec + half * h->P.stride, n_rec - half, false);
 }
 
-int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist) {
+int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist, const BinLayout* bl) {
     h->scan_hist_valid = false;  // d_hist is this batch's from here on
     if (n_rec == 0) return BRISK_HIP_OK;
     if (n_rec >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
@@ -430,7 +439,9 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         hipLaunchKernelGGL(k_part_hist, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_hist);
         if ((rc = launch_check(h, "k_part_hist"))) return rc;
     }
-    if ((rc = prefix_partitions(h, h->n_parts))) return rc;
+    // classic layout: all records go to partition order; binned layout: only the few beyond their bins do
+    const u64 n_move = bl ? bl->n_ovf : n_rec;
+    if (n_move && (rc = prefix_partitions(h, h->n_parts, bl ? bl->bin_cap : 0u))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 16, h->stream));
     {
         ProfScope ps(h, S_TOUCHED);
@@ -438,10 +449,10 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
                            (u32*)(h->d_small + 2));
         if (int lrc = launch_check(h, "k_touched")) return lrc;
     }
-    if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
-    {
+    if (n_move) {
+        if ((rc = ensure(h, h->parted, n_move * P.stride * 8))) return rc;
         ProfScope ps(h, S_SCATTER);
-        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_cur32, (u64*)h->parted.p, 0,
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_move, 256)), dim3(256), 0, h->stream, P, bl ? (const u64*)bl->ovf : d_rec, n_move, h->d_cur32, (u64*)h->parted.p, 0,
                            (const u32*)nullptr, (u32*)nullptr, h->ix.err);
         if ((rc = launch_check(h, "k_scatter"))) return rc;
     }
@@ -452,8 +463,8 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     {
         ProfScope ps(h, S_TOUCHED);
         if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
-        hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched,
-                           h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3);
+        hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, (bl && !n_move) ? (const u32*)nullptr : h->d_off,
+                           h->d_touched, n_touched, h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3, bl ? bl->bin_cap : 0u);
         if (int lrc = launch_check(h, "k_need")) return lrc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 3, h->d_small + 3, 8, hipMemcpyDeviceToHost, h->stream));
@@ -469,17 +480,18 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         // partitions of many records (few distinct minimizers: m <= 11) take the 512-instance kernel: half as many chunks, and
         // with them half as many passes over a partition's entries, outweigh its 2 waves per SIMD (k31/m11/b11: 48 -> 36 ms)
         const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
-        const bool big = n_rec / n_touched > 64;
+        const bool big = !bl && n_rec / n_touched > 64;  // (its in-place collapse needs the classic layout)
+        const RecSrc src{bl ? bl->bins : (u64*)h->parted.p, (const u64*)h->parted.p, bl ? bl->bin_cap : 0u};
         const dim3 grid(std::min<u32>(batches, big ? INSERT_SLOTS / 2 : INSERT_SLOTS));
         // instantiations with the record geometry (nw, k - b, routing-id bits kept in the key) as constants, for the
         // common parameter sets under the default partition layout; anything else takes the generic body
 #define LAUNCH_INSERT(NW, KB, SH)                                                                                                                              \
     {                                                                                                                                                          \
         if (big)                                                                                                                                               \
-            hipLaunchKernelGGL((k_insert_big<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, (u64*)h->parted.p, (const PartDesc*)h->desc.p, n_touched, h->ix, \
+            hipLaunchKernelGGL((k_insert_big<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,            \
                                (u32*)(h->d_small + 6));                                                                                                        \
         else                                                                                                                                                   \
-            hipLaunchKernelGGL((k_insert<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, (u64*)h->parted.p, (const PartDesc*)h->desc.p, n_touched, h->ix,     \
+            hipLaunchKernelGGL((k_insert<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,                \
                                (u32*)(h->d_small + 6));                                                                                                        \
     }
         static const bool generic_only = getenv("BRISK_INSERT_GENERIC") != nullptr;  // A/B and tests: force the run-time body
@@ -541,7 +553,7 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
         HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
     }
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
-    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret};
+    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret, nullptr, 0u, nullptr, 0ull, nullptr};
     const bool plain = h->scan_v1 || d_ret;
     int rc;
     u32 n_vr = 0;
@@ -733,11 +745,58 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
     return fail(h, BRISK_HIP_EHIP, "scan overflowed its exact bound");
 }
 
+// The binned insert of one batch: the scan writes every record straight into its partition's bin --
+// the rank the histogram atomic returns is the slot -- so no staging copy and no k_scatter pass exist; the few records
+// beyond a bin (bin_cap is about twice the expected mean) are moved by the classic scatter.  *applied = false when the
+// batch does not qualify (nothing has been touched then) and the classic path must take it.
+int insert_packed_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool* applied) {
+    *applied = false;
+    static const long forced = getenv("BRISK_BINS") ? atol(getenv("BRISK_BINS")) : -1;  // 0: never; S > 0: always, with bins of S records (tests)
+    if (forced == 0 || h->entry_ids || h->scan_v1 || h->P.n_owners > 1) return BRISK_HIP_OK;
+    int rc;
+    u64 bound = 0, in_long = 0;
+    if ((rc = count_kmers(h, d_starts, n_reads, &bound, &in_long))) return rc;
+    if (bound == 0 || in_long) return BRISK_HIP_OK;  // long sequences are scanned in chunks whose records are filtered afterwards
+    const u64 est = std::min<u64>(bound, 5 * bound / (2 * (h->P.w + 2)) + 2 * n_reads + 4096);  // the staging path's first guess: ~1.3x the records
+    u64 cap = forced > 0 ? (u64)forced : (2 * est / h->n_parts + 8 + 3) / 4 * 4;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const u64 bytes = h->n_parts * cap * h->P.stride * 8;
+    if (forced <= 0 && (est < 2 * h->n_parts || cap > 64 || bytes > total_b / 4)) return BRISK_HIP_OK;  // sparse batch, big partitions, or too much memory
+    if (h->n_parts * cap >= (1ull << 32)) return BRISK_HIP_OK;
+    const u64 ovf_cap = est / 8 + 65536;
+    if ((rc = ensure(h, h->bins, bytes))) return rc == BRISK_HIP_ENOMEM ? (h->err.clear(), BRISK_HIP_OK) : rc;
+    if ((rc = ensure(h, h->staging, ovf_cap * h->P.stride * 8))) return rc;
+    h->scan_hist_valid = false;
+    HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
+    ScanOut out{nullptr, 0, h->d_small, h->d_hist, (u32*)(h->d_small + 1), nullptr, nullptr, (u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, ovf_cap, h->d_small + 7};
+    ChunkCtl cc{nullptr, nullptr, nullptr, 0u};
+    if ((rc = launch_scan(h, d_packed, d_starts, n_reads, out, false, false, cc))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((u32)h->h_small[1]) return BRISK_HIP_OK;  // more records beyond the bins than the overflow buffer holds: the classic path takes the batch
+    const u64 n_rec = h->h_small[0];
+    BinLayout bl{(u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, h->h_small[7]};
+    rc = insert_records_once(h, nullptr, n_rec, true, &bl);
+    if (rc == BRISK_HIP_ENOMEM) {  // the single-pass arena reserve does not fit: the classic path can split the batch (nothing was written)
+        h->err.clear();
+        return BRISK_HIP_OK;
+    }
+    *applied = rc == BRISK_HIP_OK;
+    return rc;
+}
+
 int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads) {
     for (u64 r0 = 0; r0 < n_reads; r0 += h->max_batch_reads) {
         const u64 nb = std::min<u64>(h->max_batch_reads, n_reads - r0);
         u64 n_rec = 0;
         int rc;
+        bool binned = false;
+        if ((rc = insert_packed_binned(h, d_packed, d_starts + r0, nb, &binned))) return rc;
+        if (binned) continue;
         bool hist_ok = true;
         if ((rc = scan_to_staging(h, d_packed, d_starts + r0, nb, true, false, &n_rec, &hist_ok))) return rc;
         if ((rc = insert_records_impl(h, (const u64*)h->staging.p, n_rec, hist_ok))) return rc;
@@ -784,7 +843,7 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
     if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
     hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched, h->ix.dir,
-                       (PartDesc*)h->desc.p, h->d_small + 3);
+                       (PartDesc*)h->desc.p, h->d_small + 3, 0u);
     if (int lrc = launch_check(h, "k_need")) return lrc;
     {
         ProfScope ps(h, S_QUERY);
@@ -931,7 +990,7 @@ int drain_profile(brisk_hip_index* h) {
 void free_all(brisk_hip_index* h) {
     hipStreamSynchronize(h->stream);  // nothing of ours may be in flight when the arena is unmapped
     auto fr = [](void* p) { if (p) hipFree(p); };
-    for (DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+    for (DevBuf* b : {&h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);
@@ -1370,7 +1429,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (nb_skmers) *nb_skmers = h->nb_skmers;
     if (memory_bytes) {
         u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
-        for (const DevBuf* b : {&h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
+        for (const DevBuf* b : {&h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
                                 &h->enum_out, &h->lookup_buf})
             m += b->bytes;
         *memory_bytes = m;

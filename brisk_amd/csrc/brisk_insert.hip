@@ -90,6 +90,29 @@ __device__ __forceinline__ RecRegs load_rec_regs(const BriskParams& P, const u64
     }
     return r;
 }
+// Where a partition's records are.  Classic (bin_cap == 0): `rec` holds all records in partition order, a partition's at
+// [r_begin, r_begin + n_rec).  Binned (the scan wrote every record straight into its partition's bin):
+// record i of partition `part` is rec[part * bin_cap + i] for i < bin_cap, and ovf[r_begin + i - bin_cap] beyond (the few
+// partitions that overflow their bin; r_begin is then the partition's offset among the overflow records).
+struct RecSrc {
+    u64* rec;
+    const u64* ovf;
+    u32 bin_cap;
+};
+__device__ __forceinline__ RecRegs load_part_recs(const BriskParams& P, const RecSrc& src, u32 part, u32 r_begin, u32 first, u32 n, u32 lane) {
+    if (!src.bin_cap) return load_rec_regs(P, src.rec, first, n, lane);
+    RecRegs r{0, 0, 0, 0, 0};
+    if (lane < n) {
+        const u32 i = first - r_begin + lane;
+        const u64* c = i < src.bin_cap ? src.rec + ((u64)part * src.bin_cap + i) * P.stride : src.ovf + ((u64)r_begin + i - src.bin_cap) * P.stride;
+        r.w0 = c[0];
+        r.w1 = c[1];
+        if (P.stride > 2) r.w2 = c[2];
+        if (P.stride > 3) r.w3 = c[3];
+        if (P.stride > 4) r.w4 = c[4];
+    }
+    return r;
+}
 // Inclusive scans over the 64 lanes on the DPP network: row_shr 1,2,4,8 inside each row of 16, then row_bcast15
 // and row_bcast31 carry the row totals over.  Lanes without a source keep the identity 0.  Full EXEC mask only.
 #define WAVE_SCAN_STEP(x, OP, CTRL, ROW_MASK)                                                         \
@@ -392,8 +415,9 @@ __device__ __forceinline__ PartDesc batch_desc(const BatchDescs& m, u32 i) {  //
 // lanes and pays a v_readlane per use), and k-mers are cut out of 32-bit words (expand_and_dedupe_words).  NW == 0:
 // everything from P at run time.
 template <u32 MAXI, u32 NW, u32 KB, u32 SHIFT>
-__device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restrict__ rec, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
+__device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc& src, const PartDesc* __restrict__ desc, u32 n_touched, const IndexDev& ix,
                                             u32* __restrict__ work_counter) {
+    u64* const rec = src.rec;  // the in-place collapse of the big-partition kernel (classic layout only)
     BriskParams P = PP;
     if (NW) {  // the fields the body reads, as constants
         P.nw = NW;
@@ -435,7 +459,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
         // Under this kernel's own random traffic a dependent load takes 2-4 us of a partition's ~7 us.
         const BatchDescs mine = load_batch_descs(desc, min(t0 + lane, n_touched - 1));
         PartDesc d = batch_desc(mine, 0);
-        RecRegs rr = load_rec_regs(P, rec, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane);
+        RecRegs rr = load_part_recs(P, src, d.part, d.r_begin, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane);
 
         for (u32 t = t0; t < t_end; t++) {
             const u32 tn = t + 1;
@@ -443,7 +467,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
             RecRegs rn{0, 0, 0, 0, 0};  // first records of the next partition
             if (tn < t_end) {
                 dn = batch_desc(mine, tn - t0);
-                rn = load_rec_regs(P, rec, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
+                rn = load_part_recs(P, src, dn.part, dn.r_begin, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
             }
 
             CNT(0, 1)
@@ -460,7 +484,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
             // and far fewer chunks -- each of which streams the partition's entries -- are needed.
             // (only in the big-partition kernel: the usual one is 2-3 % slower with this path compiled in)
             bool collapsed = false;
-            if (MAXI > WI_MAX_INST && d.n_rec > 2 * WI_MAX_REC) {
+            if (MAXI > WI_MAX_INST && !src.bin_cap && d.n_rec > 2 * WI_MAX_REC) {
                 u32 wr = d.r_begin;
                 for (u32 rd = d.r_begin; rd < r_end; rd += WI_MAX_REC) {
                     const u32 avail = min(r_end - rd, (u32)WI_MAX_REC);
@@ -500,7 +524,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
                 PHASE(0)
                 CNT(1, 1)
                 const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
-                if (rc != d.r_begin) rr = load_rec_regs(P, rec, rc, avail, lane);
+                if (rc != d.r_begin) rr = load_part_recs(P, src, part, d.r_begin, rc, avail, lane);
                 wave_sync();
                 if (lane < avail) {
                     u64* dst = s_rec + lane * P.stride;
@@ -754,14 +778,14 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, u64* __restri
 
 
 template <u32 NW, u32 KB, u32 SHIFT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, RecSrc src, const PartDesc* __restrict__ desc,
                                                u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
-    insert_body<WI_MAX_INST, NW, KB, SHIFT>(P, rec, desc, n_touched, ix, work_counter);
+    insert_body<WI_MAX_INST, NW, KB, SHIFT>(P, src, desc, n_touched, ix, work_counter);
 }
 template <u32 NW, u32 KB, u32 SHIFT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, u64* __restrict__ rec, const PartDesc* __restrict__ desc,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) k_insert_big(BriskParams P, RecSrc src, const PartDesc* __restrict__ desc,
                                                                                          u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
-    insert_body<2 * WI_MAX_INST, NW, KB, SHIFT>(P, rec, desc, n_touched, ix, work_counter);
+    insert_body<2 * WI_MAX_INST, NW, KB, SHIFT>(P, src, desc, n_touched, ix, work_counter);
 }
 
 // bucket occupancy for partitions wider than 64 buckets (small part_bits): one pass over all entries

@@ -3,13 +3,18 @@
 // ===========================================================================
 // exclusive prefix sum over the low 32 bits of the 64-bit histogram
 #define SCAN_ITEMS 16
-__global__ void __launch_bounds__(256) k_psum_block(const unsigned long long* __restrict__ hist, u64 n, u32* __restrict__ block_sums) {
+// `sub`: the prefix runs over max(count, sub) - sub -- the records a partition has beyond its bin (binned layout); 0: all of them
+__device__ __forceinline__ u32 beyond(unsigned long long h, u32 sub) {
+    const u32 c = (u32)h;
+    return c > sub ? c - sub : 0u;
+}
+__global__ void __launch_bounds__(256) k_psum_block(const unsigned long long* __restrict__ hist, u64 n, u32* __restrict__ block_sums, u32 sub) {
     __shared__ u32 s[4];
     const u64 base = (u64)blockIdx.x * 256 * SCAN_ITEMS;
     u32 acc = 0;
     for (int i = 0; i < SCAN_ITEMS; i++) {
         const u64 j = base + (u64)i * 256 + threadIdx.x;
-        if (j < n) acc += (u32)hist[j];
+        if (j < n) acc += beyond(hist[j], sub);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
@@ -43,7 +48,7 @@ __global__ void __launch_bounds__(1024) k_psum_top(u32* __restrict__ block_sums,
 }
 // per block: write exclusive offsets; also seeds the scatter cursors
 __global__ void __launch_bounds__(256) k_psum_apply(const unsigned long long* __restrict__ hist, u64 n, const u32* __restrict__ block_sums,
-                                                    u32* __restrict__ off, u32* __restrict__ cursor) {
+                                                    u32* __restrict__ off, u32* __restrict__ cursor, u32 sub) {
     __shared__ u32 s_wave[4];
     const u64 base = (u64)blockIdx.x * 256 * SCAN_ITEMS + (u64)threadIdx.x * SCAN_ITEMS;
     u32 v[SCAN_ITEMS];
@@ -51,7 +56,7 @@ __global__ void __launch_bounds__(256) k_psum_apply(const unsigned long long* __
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         const u64 j = base + i;
-        v[i] = j < n ? (u32)hist[j] : 0;
+        v[i] = j < n ? beyond(hist[j], sub) : 0;
         tsum += v[i];
     }
     u32 x = tsum;
@@ -125,17 +130,24 @@ struct PartDesc {
     unsigned long long off;
 };
 __device__ __forceinline__ u32 grow_cap(u32 n) { return n + (n >> 2) + 8; }
+// bin_cap > 0 (binned layout): n_rec comes from the histogram, r_begin is the partition's offset among the overflow
+// records (part_off then holds the prefix over the records beyond the bins; null when no partition overflowed)
 __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restrict__ hist, const u32* __restrict__ part_off,
                                               const u32* __restrict__ list, u32 n_list, const DirEnt* __restrict__ dir,
-                                              PartDesc* __restrict__ desc, unsigned long long* out) {
+                                              PartDesc* __restrict__ desc, unsigned long long* out, u32 bin_cap) {
     __shared__ unsigned long long s_sum[4];
     unsigned long long need = 0;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {  // grid-stride: few blocks, few atomics
         const u32 p = list[i];
         PartDesc d;
         d.part = p;
-        d.r_begin = part_off[p];
-        d.n_rec = part_off[p + 1] - d.r_begin;
+        if (bin_cap) {
+            d.r_begin = part_off ? part_off[p] : 0u;
+            d.n_rec = (u32)hist[p];
+        } else {
+            d.r_begin = part_off[p];
+            d.n_rec = part_off[p + 1] - d.r_begin;
+        }
         d.n_inst = (u32)(hist[p] >> 32);
         const DirEnt de = dir[p];
         d.n_exist = de.cnt;

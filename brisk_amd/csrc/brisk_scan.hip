@@ -108,6 +108,13 @@ struct ScanOut {
     u32* overflow;
     u32* tag;                    // query mode: read index per record; sequence mode: position of the first k-mer (may be null)
     u64* ret;                    // sequence mode: the minimizer value next() returns with the vector (may be null)
+    // binned output (may be null; needs hist): record number i of partition p goes to bins[(p * bin_cap + i) * stride], the
+    // rank i being what the partition's histogram counter held before this record; records beyond a bin go to ovf
+    u64* bins;
+    u32 bin_cap;
+    u64* ovf;
+    u64 ovf_cap;
+    unsigned long long* n_ovf;
 };
 
 struct MiniState {
@@ -168,7 +175,7 @@ __device__ MiniState rescan_minimizer(const u32* __restrict__ packed, u64 q, u32
 // the minimizer_idx of the LAST element of the returned vector.
 __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
                                u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
-    if (slot >= out.cap) {
+    if (!out.bins && slot >= out.cap) {
         *out.overflow = 1;
         return;
     }
@@ -188,13 +195,34 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
     const W4 lowm = w4_mask(2 * cut);
     const W4 C = w4_or(w4_andn(w4_shr(S, 2 * P.b), lowm), w4_and(S, lowm));
 
-    u64* r = out.rec + slot * P.stride;
+    const u32 idx0p = idx_end - (n - 1) + P.suff_reduc;
+    u64* r;
+    if (out.bins) {
+        // One pass over the records instead of two: the histogram atomic every record pays anyway returns the record's
+        // rank in its partition, and the record goes straight to that slot of the partition's bin.  These random 32-byte
+        // stores ride along with a kernel that is bound by its vector instructions; k_scatter (209 M of the same stores and
+        // nothing else: 10-12 ms per 50 M reads) and the staging copy it read are gone.
+        const u32 part = bucket >> P.shift;
+        const u32 rank = (u32)atomicAdd(&out.hist[part], 1ull | ((unsigned long long)n << 32));
+        if (rank < out.bin_cap) {
+            r = out.bins + ((u64)part * out.bin_cap + rank) * P.stride;
+        } else {
+            const unsigned long long o = atomicAdd(out.n_ovf, 1ull);
+            if (o >= out.ovf_cap) {
+                *out.overflow = 1;
+                return;
+            }
+            r = out.ovf + o * P.stride;
+        }
+    } else {
+        r = out.rec + slot * P.stride;
+    }
     r[0] = C.w0;
     if (P.nw > 1) r[1] = C.w1;
     if (P.nw > 2) r[2] = C.w2;
     if (P.nw > 3) r[3] = C.w3;
-    const u32 idx0p = idx_end - (n - 1) + P.suff_reduc;
     r[P.nw] = rec_header(bucket, n, idx0p);
+    if (out.bins) return;
     if (out.tag) out.tag[slot] = tag;
     if (out.ret) out.ret[slot] = ret;
     if (out.hist) atomicAdd(&out.hist[bucket >> P.shift], 1ull | ((unsigned long long)n << 32));
