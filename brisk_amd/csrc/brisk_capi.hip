@@ -60,6 +60,7 @@ struct brisk_hip_index {
     double* d_coef = nullptr;
     double* d_tabs = nullptr;   // coef[128] + packed fixed-point decycling chunk tables (u64 bits), staged to LDS by k_scan2
     ScanCfg scfg{};
+    u32 insert_waves = 4096;    // most persistent k_insert waves any instantiation keeps resident (<= INSERT_SLOTS): sizes the arena reserve
     u32 scan_waves = 0;         // waves per k_scan2 block
     size_t scan_lds = 0;
     bool scan_v1 = false;       // BRISK_SCAN_V1=1: the plain restatement kernel
@@ -473,7 +474,7 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     h->arena_used_host = h->h_small[5];
     // worst case: every slice the batch may need, the tail a private chunk strands at each refill (< 1/8 of it), and
     // one partly used chunk per persistent wave
-    if ((rc = ensure_arena(h, h->h_small[3] + h->h_small[3] / 7 + (u64)INSERT_SLOTS * ARENA_CHUNK))) return rc;
+    if ((rc = ensure_arena(h, h->h_small[3] + h->h_small[3] / 7 + (u64)h->insert_waves * ARENA_CHUNK))) return rc;
     {
         ProfScope ps(h, S_INSERT);
         HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
@@ -482,23 +483,46 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
         const bool big = !bl && n_rec / n_touched > 64;  // (its in-place collapse needs the classic layout)
         const RecSrc src{bl ? bl->bins : (u64*)h->parted.p, (const u64*)h->parted.p, bl ? bl->bin_cap : 0u};
-        const dim3 grid(std::min<u32>(batches, big ? INSERT_SLOTS / 2 : INSERT_SLOTS));
+        // persistent waves: as many as the device keeps resident (the kernel's time follows their number almost linearly)
+        static const u32 wave_env = getenv("BRISK_INSERT_WAVES") ? (u32)atoi(getenv("BRISK_INSERT_WAVES")) : 0u;  // experiments
+        auto resident = [&](const void* fn) -> u32 {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
+            const u32 w = std::min<u32>((u32)per_cu * (u32)cus, h->insert_waves);
+            static const bool dbg = getenv("BRISK_DEBUG_INSERT") != nullptr;
+            if (dbg) fprintf(stderr, "[brisk_hip] k_insert: %d waves per CU x %d CUs resident, %u launched\n", per_cu, cus, wave_env ? std::min<u32>(w, wave_env) : w);
+            return wave_env ? std::min<u32>(w, wave_env) : w;
+        };
         // instantiations with the record geometry (nw, k - b, routing-id bits kept in the key) as constants, for the
         // common parameter sets under the default partition layout; anything else takes the generic body
-#define LAUNCH_INSERT(NW, KB, SH)                                                                                                                              \
-    {                                                                                                                                                          \
-        if (big)                                                                                                                                               \
-            hipLaunchKernelGGL((k_insert_big<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,            \
-                               (u32*)(h->d_small + 6));                                                                                                        \
-        else                                                                                                                                                   \
-            hipLaunchKernelGGL((k_insert<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,                \
-                               (u32*)(h->d_small + 6));                                                                                                        \
+#define LAUNCH_INSERT(NW, KB, SH)                                                                                                                                   \
+    {                                                                                                                                                               \
+        if (big) {                                                                                                                                                  \
+            const dim3 grid(std::min<u32>(batches, resident((const void*)k_insert_big<NW, KB, SH>)));                                                             \
+            hipLaunchKernelGGL((k_insert_big<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,                    \
+                               (u32*)(h->d_small + 6));                                                                                                             \
+        } else {                                                                                                                                                    \
+            const dim3 grid(std::min<u32>(batches, resident((const void*)k_insert<NW, KB, SH>)));                                                                 \
+            hipLaunchKernelGGL((k_insert<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,                        \
+                               (u32*)(h->d_small + 6));                                                                                                             \
+        }                                                                                                                                                           \
+    }
+#define LAUNCH_INSERT_FAST(NW, KB, SH)                                                                                                                              \
+    {                                                                                                                                                               \
+        if (big) LAUNCH_INSERT(NW, KB, SH)                                                                                                                          \
+        else {                                                                                                                                                      \
+            const dim3 grid(std::min<u32>(batches, resident((const void*)k_insert_fast<NW, KB, SH>)));                                                            \
+            hipLaunchKernelGGL((k_insert_fast<NW, KB, SH>), grid, dim3(64), 0, h->stream, P, src, (const PartDesc*)h->desc.p, n_touched, h->ix,                   \
+                               (u32*)(h->d_small + 6));                                                                                                             \
+        }                                                                                                                                                           \
     }
         static const bool generic_only = getenv("BRISK_INSERT_GENERIC") != nullptr;  // A/B and tests: force the run-time body
-        if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_INSERT(3, 49, 4)        // k63 m21 b14
-        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_INSERT(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
-        else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_INSERT(2, 20, 0)  // k31 m11 b11
+        if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_INSERT_FAST(3, 49, 4)        // k63 m21 b14
+        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_INSERT_FAST(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_INSERT_FAST(2, 20, 0)  // k31 m11 b11
         else LAUNCH_INSERT(0, 0, 0)
+#undef LAUNCH_INSERT_FAST
 #undef LAUNCH_INSERT
         if ((rc = launch_check(h, big ? "k_insert_big" : "k_insert"))) return rc;
     }
@@ -1140,6 +1164,16 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             }
             const char* v1 = getenv("BRISK_SCAN_V1");
             h->scan_v1 = v1 && v1[0] == '1';
+        }
+        {   // the persistent insert kernels: how many waves the device keeps resident, at most
+            const void* fns[] = {(const void*)k_insert<0, 0, 0>, (const void*)k_insert_big<0, 0, 0>, (const void*)k_insert_fast<3, 49, 4>, (const void*)k_insert_fast<2, 17, 4>,
+                                 (const void*)k_insert_fast<2, 20, 0>, (const void*)k_insert_big<3, 49, 4>, (const void*)k_insert_big<2, 17, 4>, (const void*)k_insert_big<2, 20, 0>};
+            int most = 16;
+            for (const void* fn : fns) {
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) == hipSuccess && per_cu > most) most = per_cu;
+            }
+            h->insert_waves = std::min<u32>((u32)most * (u32)prop.multiProcessorCount, INSERT_SLOTS);
         }
         const u64 np = h->n_parts;
         HIPCHK(h, hipMalloc((void**)&h->ix.dir, np * sizeof(DirEnt)));

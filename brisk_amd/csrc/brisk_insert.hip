@@ -24,7 +24,7 @@
 // 2 waves per SIMD, 61 ms instead of 50 ms on the 50M-read job; 128-instance chunks spill and split
 // too many partitions: 84 ms).
 #ifndef INSERT_SLOTS
-#define INSERT_SLOTS 4096u   // persistent waves == private allocator slots (256 CUs x 4 SIMDs x 4 waves)
+#define INSERT_SLOTS 8192u   // private allocator slots: an upper bound of the persistent waves (256 CUs x 4 SIMDs x 8 waves)
 #endif
 #ifndef WI_WAVES_PER_EU
 #define WI_WAVES_PER_EU 4
@@ -263,14 +263,26 @@ __device__ __forceinline__ void store_rec_words(u32* dst, const RecRegs& rr, u32
     dst[RecGeom<NW>::INFO] = info;
     dst[RecGeom<NW>::INFO + 1] = 0;  // read (and shifted out) by the last k-mer's window
 }
-template <u32 NI, u32 NW, u32 KB, u32 SHIFT>
+// What a lane keeps of its instances for the append (register arrays, compile-time indices only): their keys, the table
+// slot each ended up in, and which of them CREATED their slot (the first copy of a key).
+template <u32 NIMAX>
+struct LaneInst {
+    u64 klo[NIMAX], khi[NIMAX];
+    u32 hh[NIMAX];
+    u32 won;
+};
+template <u32 NI, u32 NW, u32 KB, u32 SHIFT, u32 NIMAX>
 __device__ __forceinline__ void expand_and_dedupe_words(u32 lane, u32 ninst, u32 tsize, const u32* s_rw, const uint8_t* s_irec, const u32* s_rmult,
-                                                        u64* s_key, u32* s_tab, u32* dbg_rounds) {
+                                                        u64* s_key, u32* s_tab, u32* dbg_rounds, LaneInst<NIMAX>& li) {
     constexpr u32 RS = RecGeom<NW>::RS, INFO = RecGeom<NW>::INFO, KBITS = 2 * KB + 6;
     static_assert(KBITS + SHIFT <= 128 && SHIFT <= 6, "entry key: [routing id low bits | compacted k-mer | idx']");
-    u64 klo[NI], khi[NI];
-    u32 hh[NI], mult[NI];
+    static_assert(NI <= NIMAX, "instances per lane");
+    u64 (&klo)[NIMAX] = li.klo;
+    u64 (&khi)[NIMAX] = li.khi;
+    u32 (&hh)[NIMAX] = li.hh;
+    u32 mult[NI];
     u32 rix[NI];
+    u32 won = 0;
 #pragma unroll
     for (u32 it = 0; it < NI; it++) {
         const u32 i = it * 64 + lane;
@@ -312,6 +324,8 @@ __device__ __forceinline__ void expand_and_dedupe_words(u32 lane, u32 ninst, u32
             s_key[2 * i + 1] = hi;
         }
     }
+    wave_sync();  // every lane has read its records: the table may take their place
+    for (u32 w = 0; w * 64 < tsize; w++) s_tab[w * 64 + lane] = EMPTY_SLOT;
     wave_sync();
     u32 pending = 0;
 #pragma unroll
@@ -337,6 +351,7 @@ __device__ __forceinline__ void expand_and_dedupe_words(u32 lane, u32 ninst, u32
             if (pending >> it & 1) {
                 if (old[it] == EMPTY_SLOT) {
                     pending &= ~(1u << it);
+                    won |= 1u << it;
                 } else if (olo[it] == klo[it] && ohi[it] == khi[it]) {
                     atomicAdd(&s_tab[hh[it]], mult[it]);
                     pending &= ~(1u << it);
@@ -346,6 +361,7 @@ __device__ __forceinline__ void expand_and_dedupe_words(u32 lane, u32 ninst, u32
             }
         }
     }
+    li.won = won;
 }
 
 // Record-level de-duplication of the <= 64 records the lanes hold (also in s_rec): the first copy of every distinct record
@@ -427,19 +443,33 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
     }
     constexpr u32 TABLE = 2 * MAXI, TS = TABLE / 64, NI = MAXI / 64;
     static_assert(MAXI % 256 == 0 && MAXI <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
-    __shared__ u64 s_key[2 * MAXI];
-    // records as u64 words (record-level de-duplication), then -- NW > 0 -- again as shifted 32-bit words (+4: the last
-    // record's window reads up to two words past its slot), then the list of new entries
+    // LDS of one wave, one buffer cut into regions.  k_insert's throughput follows the number of resident waves almost
+    // linearly (4096 -> 30.8 ms, 3072 -> 38.3, 2048 -> 54.2, 1024 -> 103.6 per 50 M reads: every wave is a serial chain of
+    // LDS and memory round trips), so what is not live at the same time shares its bytes.  Compile-time geometry (NW > 0):
+    // the probe table lies over the records' region -- the records are last read when the keys are built, the table is
+    // first written right after -- and nothing of the generic body's prefix array exists: 7,680 B per wave instead of
+    // 10,000, i.e. 21 waves per CU by LDS instead of 16.
+    //   s_key   [2 * MAXI] u64   the instances' keys                          expand .. stream
+    //   s_rec   [REC_U64]  u64   records as u64 words (record-level pass), then as shifted 32-bit words (s_rw; + 4 words:
+    //                            the last record's window reads two words past its slot), generic: then the new entries' list
+    //   s_tab   [TABLE]    u32   probe table                                   NW > 0: over s_rec
+    //   s_rtab, s_rmult, s_irec, (generic: s_pref)
     constexpr u32 REC_U64 = WI_MAX_REC * 5 > MAXI / 2 ? WI_MAX_REC * 5 : MAXI / 2;
-    __shared__ u64 s_rec[REC_U64];
     static_assert(NW == 0 || (WI_MAX_REC * RecGeom<NW ? NW : 1>::RS + 4) * 4 <= REC_U64 * 8, "shifted record words must fit the record buffer");
+    constexpr bool TAB_OVER_REC = NW && TABLE * 4 <= REC_U64 * 8;  // (the 512-instance body's table is larger than its record buffer)
+    constexpr u32 OFF_REC = 16 * MAXI, OFF_TAB = TAB_OVER_REC ? OFF_REC : OFF_REC + 8 * REC_U64, OFF_RTAB = TAB_OVER_REC ? OFF_REC + 8 * REC_U64 : OFF_TAB + 4 * TABLE;
+    constexpr u32 OFF_RMULT = OFF_RTAB + 4 * 2 * WI_MAX_REC, OFF_IREC = OFF_RMULT + 4 * WI_MAX_REC, OFF_PREF = OFF_IREC + MAXI;
+    constexpr u32 LDS_BYTES = NW ? OFF_PREF : OFF_PREF + 4 * (WI_MAX_REC + 1) + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
+    u64* s_key = (u64*)s_mem;
+    u64* s_rec = (u64*)(s_mem + OFF_REC);
     u32* s_rw = (u32*)s_rec;
-    __shared__ u32 s_tab[TABLE];
-    __shared__ u32 s_pref[WI_MAX_REC + 1];
-    u32* s_list = (u32*)s_rec;  // [MAXI] the new entries' table words: built after the records have been expanded
-    __shared__ u32 s_rtab[2 * WI_MAX_REC];
-    __shared__ u32 s_rmult[WI_MAX_REC];
-    __shared__ __attribute__((aligned(4))) uint8_t s_irec[MAXI];
+    u32* s_tab = (u32*)(s_mem + OFF_TAB);
+    u32* s_list = (u32*)s_rec;  // generic body: [MAXI] the new entries' table words, built after the records have been expanded
+    u32* s_rtab = (u32*)(s_mem + OFF_RTAB);
+    u32* s_rmult = (u32*)(s_mem + OFF_RMULT);
+    uint8_t* s_irec = s_mem + OFF_IREC;
+    u32* s_pref = (u32*)(s_mem + (NW ? 0 : OFF_PREF));  // generic body only
 
     const u32 lane = threadIdx.x;
     PHASE_DECL
@@ -562,11 +592,14 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                 const u32 raw_inst = __shfl(x0, nrec - 1, 64);
                 u32 tsize = 128;
                 while (tsize < 2 * ninst && tsize < TABLE) tsize <<= 1;
-                s_pref[lane + 1] = x;
-                if (lane == 0) s_pref[0] = 0;
+                if (!NW) {  // (compile-time geometry: the prefix travels in the records' info words, and the table -- which lies
+                            // over the records there -- is cleared once the keys have been built from them)
+                    s_pref[lane + 1] = x;
+                    if (lane == 0) s_pref[0] = 0;
 #pragma unroll
-                for (u32 w = 0; w < TS; w++)
-                    if (w * 64 < tsize) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                    for (u32 w = 0; w < TS; w++)
+                        if (w * 64 < tsize) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                }
                 {
                     // instance -> record: each record marks its first instance, a running maximum spreads the marks
                     // (records lie in lane order).  Every lane owns MAXI/64 consecutive instances here.
@@ -596,6 +629,8 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                 // ---- 0/1. expand to entry keys and de-duplicate
                 PHASE(2)
                 u32 dbg_r = 0;
+                LaneInst<NI> li;
+                li.won = 0;
                 CNT(3, (ninst + 63) / 64)
                 CNT(4, ninst)
                 CNT(5, nrec)
@@ -607,11 +642,11 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                         store_rec_words<NW ? NW : 1>(s_rw + lane * RecGeom<NW ? NW : 1>::RS, rr, info);
                     }
                     wave_sync();
-                    if (ninst <= 64) expand_and_dedupe_words<1, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
-                    else if (ninst <= 128) expand_and_dedupe_words<2, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
-                    else if (ninst <= 192) expand_and_dedupe_words<3, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
-                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe_words<4, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
-                    else expand_and_dedupe_words<NI, NW ? NW : 1, KB, SHIFT>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r);
+                    if (ninst <= 64) expand_and_dedupe_words<1, NW ? NW : 1, KB, SHIFT, NI>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r, li);
+                    else if (ninst <= 128) expand_and_dedupe_words<2, NW ? NW : 1, KB, SHIFT, NI>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r, li);
+                    else if (ninst <= 192) expand_and_dedupe_words<3, NW ? NW : 1, KB, SHIFT, NI>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r, li);
+                    else if (NI <= 4 || ninst <= 256) expand_and_dedupe_words<4, NW ? NW : 1, KB, SHIFT, NI>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r, li);
+                    else expand_and_dedupe_words<NI, NW ? NW : 1, KB, SHIFT, NI>(lane, ninst, tsize, s_rw, s_irec, s_rmult, s_key, s_tab, &dbg_r, li);
                 } else {
                     if (ninst <= 128) expand_and_dedupe<2, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
                     else if (NI <= 4 || ninst <= 256) expand_and_dedupe<4, 0>(P, lane, ninst, tsize, s_rec, s_pref, s_irec, s_rmult, s_key, s_tab);
@@ -661,17 +696,38 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                 wave_sync();
 
                 PHASE(5)
-                // ---- 3. append the unmatched ones: compact them in LDS, then write them out with
-                // full waves (a store instruction costs the same with 3 active lanes as with 64)
+                // ---- 3. append the unmatched ones.  Generic body: the table is swept, the new entries' table words are
+                // compacted in LDS and written out by full waves.  Compile-time geometry: every lane still holds its
+                // instances' keys and slots and knows which of them created their slot, so the new entries are ranked with
+                // one ballot per instance slot and written straight from registers -- no sweep of the table (8 rounds for
+                // 512 slots), no list, no keys read back from LDS: 160 -> ~75 vector instructions per partition.
                 u32 n_new = 0;
+                u32 new_mask = 0, new_rank[NI], new_word[NI];
+                if (NW) {
 #pragma unroll
-                for (u32 w = 0; w < TS; w++) {
-                    if (w * 64 < tsize) {
-                        const u32 v = s_tab[w * 64 + lane];
-                        const bool is_new = v != EMPTY_SLOT && !(v & MATCHED_BIT);
-                        const unsigned long long bal = __ballot(is_new);
-                        if (is_new) s_list[n_new + (u32)__popcll(bal & lanes_below(lane))] = v;
-                        n_new += (u32)__popcll(bal);
+                    for (u32 it = 0; it < NI; it++) {
+                        new_rank[it] = 0;
+                        new_word[it] = 0;
+                        if (it * 64 < ninst) {  // wave-uniform
+                            const bool made = (li.won >> it) & 1;
+                            if (made) new_word[it] = s_tab[li.hh[it]];
+                            const bool is_new = made && !(new_word[it] & MATCHED_BIT);
+                            const unsigned long long bal = __ballot(is_new);
+                            new_rank[it] = n_new + (u32)__popcll(bal & lanes_below(lane));
+                            if (is_new) new_mask |= 1u << it;
+                            n_new += (u32)__popcll(bal);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (u32 w = 0; w < TS; w++) {
+                        if (w * 64 < tsize) {
+                            const u32 v = s_tab[w * 64 + lane];
+                            const bool is_new = v != EMPTY_SLOT && !(v & MATCHED_BIT);
+                            const unsigned long long bal = __ballot(is_new);
+                            if (is_new) s_list[n_new + (u32)__popcll(bal & lanes_below(lane))] = v;
+                            n_new += (u32)__popcll(bal);
+                        }
                     }
                 }
                 wave_sync();
@@ -720,18 +776,33 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                     off = noff;
                 }
                 PHASE(7)
-                for (u32 q = lane; q < n_new; q += 64) {
-                    const u32 v = s_list[q];
-                    const u32 i = v & WI_IDX_MASK;
-                    const u64 klo2 = s_key[2 * i], khi2 = s_key[2 * i + 1];
-                    const unsigned long long at = off + n_exist + q;
-                    ix.keys[2 * at] = klo2;
-                    ix.keys[2 * at + 1] = khi2;
-                    ix.counts[at] = (uint8_t)(v >> WI_CNT_SHIFT);
-                    // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here)
-                    const u32 bl = P.shift ? ((u32)shr128(mk128(klo2, khi2), kbits).lo & ((1u << P.shift) - 1)) : 0;
-                    const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;  // 64 bins at most
-                    if (bb < 32) bm0 |= 1u << bb; else bm1 |= 1u << (bb - 32);
+                if (NW) {
+#pragma unroll
+                    for (u32 it = 0; it < NI; it++) {
+                        if ((new_mask >> it) & 1) {
+                            const unsigned long long at = off + n_exist + new_rank[it];
+                            ix.keys[2 * at] = li.klo[it];
+                            ix.keys[2 * at + 1] = li.khi[it];
+                            ix.counts[at] = (uint8_t)(new_word[it] >> WI_CNT_SHIFT);
+                            const u32 bl = P.shift ? ((u32)shr128(mk128(li.klo[it], li.khi[it]), kbits).lo & ((1u << P.shift) - 1)) : 0;
+                            const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;  // 64 bins at most
+                            if (bb < 32) bm0 |= 1u << bb; else bm1 |= 1u << (bb - 32);
+                        }
+                    }
+                } else {
+                    for (u32 q = lane; q < n_new; q += 64) {
+                        const u32 v = s_list[q];
+                        const u32 i = v & WI_IDX_MASK;
+                        const u64 klo2 = s_key[2 * i], khi2 = s_key[2 * i + 1];
+                        const unsigned long long at = off + n_exist + q;
+                        ix.keys[2 * at] = klo2;
+                        ix.keys[2 * at + 1] = khi2;
+                        ix.counts[at] = (uint8_t)(v >> WI_CNT_SHIFT);
+                        // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here)
+                        const u32 bl = P.shift ? ((u32)shr128(mk128(klo2, khi2), kbits).lo & ((1u << P.shift) - 1)) : 0;
+                        const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;  // 64 bins at most
+                        if (bb < 32) bm0 |= 1u << bb; else bm1 |= 1u << (bb - 32);
+                    }
                 }
                 n_exist += n_new;
                 rc += nrec;
@@ -777,6 +848,15 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
 }
 
 
+#ifndef WI_WAVES_PER_EU_FAST
+#define WI_WAVES_PER_EU_FAST 4   // 5 (<= 96 registers) spills 18 of them: 35.0 ms at 4096 waves, 30.3 at 5120 -- no better than 4 waves without scratch (30.4)
+#endif
+template <u32 NW, u32 KB, u32 SHIFT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU_FAST, 8))) k_insert_fast(BriskParams P, RecSrc src, const PartDesc* __restrict__ desc,
+                                                                                                        u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
+    static_assert(NW > 0, "compile-time record geometry");
+    insert_body<WI_MAX_INST, NW, KB, SHIFT>(P, src, desc, n_touched, ix, work_counter);
+}
 template <u32 NW, u32 KB, u32 SHIFT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU, 8))) k_insert(BriskParams P, RecSrc src, const PartDesc* __restrict__ desc,
                                                u32 n_touched, IndexDev ix, u32* __restrict__ work_counter) {
