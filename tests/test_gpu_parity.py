@@ -642,3 +642,14 @@ def test_arena_reuse_across_many_indexes(B, O):
             assert mi["retired_va"] == retired0, "an arena was retired although the pool had room"
     with B.BriskHip(k, m, b) as ix:
         assert ix.memory_info()["pooled"] == 0 or True  # the arena just taken came out of the pool; others may still be in it
+
+
+def test_gpu_against_the_reference_build_itself(B, R):
+    """the HIP path against oracle/_ref -- the reference's OWN Kmers.cpp / hashing.cpp / Decycling.cpp
+    and Bucket<DATA> / SKL, compiled where they lie -- with no restatement in between (every other parity test goes
+    through oracle/brisk_oracle.c, which is itself pinned by the same build).  Skipped where the reference build did
+    not travel."""
+    rng = random.Random(91)
+    reads = _random_reads(rng, 600, 8000) + SPECIAL
+    for k, m, b in ((63, 21, 14), (31, 11, 4), (31, 15, 14)):
+        assert gpu_count(B, reads, k, m, b, batches=3) == R.count(reads, k, m, b), (k, m, b)
