@@ -481,7 +481,8 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         // partitions of many records (few distinct minimizers: m <= 11) take the 512-instance kernel: half as many chunks, and
         // with them half as many passes over a partition's entries, outweigh its 2 waves per SIMD (k31/m11/b11: 48 -> 36 ms)
         const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
-        const bool big = !bl && n_rec / n_touched > 64;  // (its in-place collapse needs the classic layout)
+        static const u64 big_at = getenv("BRISK_INSERT_BIG_AT") ? (u64)atoll(getenv("BRISK_INSERT_BIG_AT")) : 64ull;  // experiments
+        const bool big = !bl && n_rec / n_touched > big_at;  // (its in-place collapse needs the classic layout)
         const RecSrc src{bl ? bl->bins : (u64*)h->parted.p, (const u64*)h->parted.p, bl ? bl->bin_cap : 0u};
         // persistent waves: as many as the device keeps resident (the kernel's time follows their number almost linearly)
         static const u32 wave_env = getenv("BRISK_INSERT_WAVES") ? (u32)atoi(getenv("BRISK_INSERT_WAVES")) : 0u;  // experiments
@@ -537,7 +538,12 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
                 const ChunkCtl& cc) {
     ProfScope ps(h, S_SCAN);
     if (plain) {  // sequence mode needs the minimizer values: the plain kernel carries them
-        hipLaunchKernelGGL(k_scan, dim3(nblocks(n_items, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, h->P, d_packed, d_starts, n_items, h->d_coef,
+        BriskParams P = h->P;
+        if (out.ret) {  // and whole vectors: see brisk_hip_scan_sequence
+            P.ext_bits -= P.cls_bits;
+            P.cls_bits = 0;
+        }
+        hipLaunchKernelGGL(k_scan, dim3(nblocks(n_items, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, h->stream, P, d_packed, d_starts, n_items, h->d_coef,
                            out, query_mode ? 1 : 0);
     } else {
         const u32 bt = h->scan_waves * 64;
@@ -742,6 +748,14 @@ int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out, 
     return BRISK_HIP_OK;
 }
 
+// first guess at the records `bound` k-mers of n_reads reads become: one per ~(w+2)/2 k-mers (a quarter more, for slack), the one
+// that ends every read, and with minimizer_idx classes a cut every cls_width k-mers
+static u64 records_estimate(const brisk_hip_index* h, u64 bound, u64 n_reads) {
+    u64 est = 5 * bound / (2 * (h->P.w + 2)) + 2 * n_reads + 4096;
+    if (h->P.cls_bits) est += 5 * bound / (4 * h->P.cls_width);
+    return std::min<u64>(bound, est);
+}
+
 // scan a batch into the staging buffer, retrying once with the exact bound
 int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool with_hist, bool query_mode,
                     u64* n_rec_out, bool* hist_valid = nullptr) {
@@ -752,9 +766,8 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
         *n_rec_out = 0;
         return BRISK_HIP_OK;
     }
-    // first try: a record per ~(w+2)/2 k-mers (a quarter more, for slack) and the one that ends every read
     (void)in_long;
-    u64 cap = std::min<u64>(bound, 5 * bound / (2 * (h->P.w + 2)) + 2 * n_reads + 4096);
+    u64 cap = records_estimate(h, bound, n_reads);
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = ensure(h, h->staging, cap * h->P.stride * 8))) return rc;
         u32* tags = nullptr;
@@ -777,11 +790,14 @@ int insert_packed_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_s
     *applied = false;
     static const long forced = getenv("BRISK_BINS") ? atol(getenv("BRISK_BINS")) : -1;  // 0: never; S > 0: always, with bins of S records (tests)
     if (forced == 0 || h->entry_ids || h->scan_v1 || h->P.n_owners > 1) return BRISK_HIP_OK;
+    // minimizers short enough for class bits are few and unevenly used: a tenth of the partitions hold everything, and bins sized for
+    // the mean overflow
+    if (forced < 0 && h->P.cls_bits) return BRISK_HIP_OK;
     int rc;
     u64 bound = 0, in_long = 0;
     if ((rc = count_kmers(h, d_starts, n_reads, &bound, &in_long))) return rc;
     if (bound == 0 || in_long) return BRISK_HIP_OK;  // long sequences are scanned in chunks whose records are filtered afterwards
-    const u64 est = std::min<u64>(bound, 5 * bound / (2 * (h->P.w + 2)) + 2 * n_reads + 4096);  // the staging path's first guess: ~1.3x the records
+    const u64 est = records_estimate(h, bound, n_reads);  // the staging path's first guess: ~1.3x the records
     u64 cap = forced > 0 ? (u64)forced : (2 * est / h->n_parts + 8 + 3) / 4 * 4;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1083,8 +1099,23 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     // Partitions: by default up to 2^24 of them whatever b is -- a small b leaves few buckets, so records are routed
     // by the bucket id plus ext_bits more bits of the same hashed minimizer (at most what it has: 2m - 2b, and what
     // the record header has room for).  An explicit part_bits keeps plain bucket ranges.
-    P.ext_bits = 0;
-    if (!o.part_bits && 2u * b < 24u) P.ext_bits = std::min<u32>(std::min<u32>(24u - 2u * b, 2u * (m - b)), 16u);
+    // A minimizer of fewer than 12 nts has fewer than 24 hash bits to give: the partitions of such an index are few and
+    // big (k=31 m=11 b=11: 4 M buckets holding what the default geometry spreads over 16 M partitions, and the most
+    // frequent minimizers far more).  minimizer_idx is part of an entry's identity (SuperKmerLight.hpp:209-217), so its
+    // class floor(minimizer_idx / cls_width) can extend the routing id like a hash bit does; the scan cuts a
+    // super-k-mer's record where the class changes (brisk_scan.hip, emit_record_at).
+    P.ext_bits = P.cls_bits = 0;
+    P.cls_width = 1;
+    if (!o.part_bits && 2u * b < 24u) {
+        static const long cls_env = getenv("BRISK_CLS_BITS") ? atol(getenv("BRISK_CLS_BITS")) : -1;
+        // One class bit: each one multiplies the records (k=31 m=11 b=11, 10 M reads: 120 M records whole, 230 M cut in two classes,
+        // 320 M in four) and scan + scatter grow with them, while the insert has what it needs once the partitions fit its
+        // LDS table: 48.3 ms per batch without, 34.9 with one bit, 47.0 with two, 73.0 with three (BRISK_CLS_BITS, profiles/r02_cls_sweep.txt).
+        if (2u * m < 24u && P.w + 1 >= 8) P.cls_bits = cls_env >= 0 ? std::min<u32>((u32)cls_env, 3u) : 1u;
+        const u32 from_hash = std::min<u32>(std::min<u32>(24u - 2u * b, 2u * (m - b)), 16u - P.cls_bits);
+        P.ext_bits = from_hash + P.cls_bits;
+        if (P.cls_bits) P.cls_width = (P.w + 1 + (1u << P.cls_bits) - 1) >> P.cls_bits;
+    }
     const u32 rbits = 2u * b + P.ext_bits;
     P.part_bits = o.part_bits ? std::min<u32>(o.part_bits, 2u * b) : std::min<u32>(rbits, 24u);
     P.shift = rbits - P.part_bits;
@@ -1299,6 +1330,8 @@ BRISK_API int brisk_hip_get_layout(const brisk_hip_index* h, brisk_hip_layout* o
     out->record_words = P.stride;
     out->part_bits = P.part_bits;
     out->ext_bits = P.ext_bits;
+    out->cls_bits = P.cls_bits;
+    out->cls_width = P.cls_width;
     out->n_owners = P.n_owners;
     out->owner_rank = P.owner_rank;
     return BRISK_HIP_OK;
@@ -1749,7 +1782,11 @@ BRISK_API int brisk_hip_scan_sequence(brisk_hip_index* h, const char* bases, uin
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     const uint64_t offs[2] = {0, len};
-    const BriskParams& P = h->P;
+    // SuperKmerEnumerator::next yields whole vectors: no minimizer_idx classes in the routing ids of this scan (they are not used:
+    // the records only carry the vectors to k_expand_records)
+    BriskParams P = h->P;
+    P.ext_bits -= P.cls_bits;
+    P.cls_bits = 0;
     const u32 row = P.w + 1;
     return for_each_host_batch(h, bases, offs, 1, [&](u64, u64) -> int {
         int rc;

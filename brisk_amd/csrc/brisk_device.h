@@ -20,7 +20,13 @@ struct BriskParams {
     u32 nw;          // u64 words holding a compacted super-k-mer (2k-m-b nts)
     u32 stride;      // nw + 1: record words, last one is the header
     u32 part_bits;   // log2(#partitions)
-    u32 ext_bits;    // minimizer-hash bits beyond the bucket's that route a record (0 once 2b >= 24): rid = bucket << ext_bits | extra
+    u32 ext_bits;    // routing-id bits beyond the bucket's (0 once 2b >= 24): rid = bucket << ext_bits | extra.  The extra bits are
+                     // more bits of the same hashed minimizer and, below them, cls_bits of the k-mer's minimizer_idx class
+    u32 cls_bits;    // m so small that the minimizer hash runs out of bits before there are 2^24 routing ids (2m < 24): the
+                     // class floor(minimizer_idx / cls_width) of a k-mer extends its routing id.  Few distinct minimizers
+                     // mean big partitions; k-mers of different minimizer_idx never meet, so the classes cut every such
+                     // partition into 2^cls_bits independent ones, and the scan cuts a super-k-mer's record where the class changes
+    u32 cls_width;
     u32 shift;       // 2b + ext_bits - part_bits: routing-id bits kept inside an entry key
     u32 n_owners, owner_rank;
     u64 m_mask;      // 2m ones
@@ -238,13 +244,23 @@ __device__ __forceinline__ u64 order_key(u64 x, u32 m, u64 M, const double* coef
 }
 
 // ---------------------------------------------------------------------------
-// routing id of a hashed minimizer h (2m bits): [bucket (2b bits, Brisk.hpp:135-137) | ext_bits of what is left of h:
-// the 2*suff_reduc bits below the bucket first, then the bits above it]
-__device__ __forceinline__ u32 routing_id(const BriskParams& P, u64 h) {
+// routing id of a k-mer with hashed minimizer h (2m bits) and minimizer_idx: [bucket (2b bits, Brisk.hpp:135-137) | bits of what is
+// left of h: the 2*suff_reduc bits below the bucket first, then the bits above it | cls_bits: the class of minimizer_idx]
+__device__ __forceinline__ u32 cls_of(const BriskParams& P, u32 minimizer_idx) {
+    const u32 c = minimizer_idx / P.cls_width, top = (1u << P.cls_bits) - 1;
+    return c < top ? c : top;
+}
+// the routing id without its class bits
+__device__ __forceinline__ u32 routing_base(const BriskParams& P, u64 h) {
     const u32 bucket = (u32)((h >> (2 * P.suff_reduc)) & P.bucket_mask);
-    if (!P.ext_bits) return bucket;
+    const u32 he = P.ext_bits - P.cls_bits;  // bits taken from what is left of the hash
+    if (!he) return bucket;
     const u64 rest = ((h >> (2 * (P.suff_reduc + P.b))) << (2 * P.suff_reduc)) | (h & ((1ull << (2 * P.suff_reduc)) - 1));
-    return (bucket << P.ext_bits) | (u32)(rest & ((1u << P.ext_bits) - 1));
+    return (bucket << he) | (u32)(rest & ((1u << he) - 1));
+}
+__device__ __forceinline__ u32 routing_id(const BriskParams& P, u64 h, u32 minimizer_idx) {
+    const u32 base = routing_base(P, h);
+    return P.cls_bits ? (base << P.cls_bits) | cls_of(P, minimizer_idx) : base;
 }
 // entry key inside a partition: [routing id low `shift` bits | compacted k-mer (2kb) | idx' (6)]
 __device__ __forceinline__ u128x make_key(const BriskParams& P, u32 bucket, u128x comp, u32 idxp) {

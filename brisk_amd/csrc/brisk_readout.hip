@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
     if (idx <= P.w) {
         const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
         const u64 h = mix2m(mm, P.m_mask);
-        const u32 bucket = routing_id(P, h);
+        const u32 bucket = routing_id(P, h, idx);
         km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
         const u32 cut = idx + P.suff_reduc;
         const u128x lowm = mask128(2 * cut);
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
 __device__ __forceinline__ u128x key_of_kmer(const BriskParams& P, u128x km, u32 idx, u32* part, u32* bucket_out) {
     const u64 mm = shr128(km, 2 * idx).lo & P.m_mask;
     const u64 h = mix2m(mm, P.m_mask);
-    const u32 bucket = routing_id(P, h);
+    const u32 bucket = routing_id(P, h, idx);
     km = or128(andn128(km, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(h, 0), 2 * idx));
     const u32 cut = idx + P.suff_reduc;
     const u128x lowm = mask128(2 * cut);

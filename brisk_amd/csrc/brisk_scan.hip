@@ -170,12 +170,21 @@ __device__ MiniState rescan_minimizer(const u32* __restrict__ packed, u64 q, u32
     return s;
 }
 
-// Build and append the record of one super-k-mer: k-mers at read positions
+// records a super-k-mer becomes: one, or -- where minimizer_idx classes extend the routing id (BriskParams::cls_bits) -- one
+// per class its k-mers fall into (their minimizer_idx rises by one per element: idx_end - (n - 1) .. idx_end)
+template <bool CLS>
+__device__ __forceinline__ u32 superkmer_pieces(const BriskParams& P, u32 n, u32 idx_end) {
+    return (CLS ? P.cls_bits : 0u) ? cls_of(P, idx_end) - cls_of(P, idx_end - (n - 1)) + 1 : 1u;
+}
+
+// Build and append the record(s) of one super-k-mer: k-mers at read positions
 // [p0, p0+n), vector reversed if `rev` (Kmers.cpp:554-556,597-599); idx_end is
-// the minimizer_idx of the LAST element of the returned vector.
+// the minimizer_idx of the LAST element of the returned vector.  `slot`: the first of superkmer_pieces() consecutive
+// slots (classic output); binned output takes its slots from the partitions' histogram counters.
+template <bool CLS>  // CLS false: the caller knows there are no minimizer_idx classes (m >= 12)
 __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
                                u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
-    if (!out.bins && slot >= out.cap) {
+    if (!out.bins && slot + superkmer_pieces<CLS>(P, n, idx_end) > out.cap) {
         *out.overflow = 1;
         return;
     }
@@ -186,7 +195,7 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
     // of the last one (hash_kmer_minimizer_inplace re-extracts it, Kmers.cpp:191-200)
     const u64 mm = w4_shr(S, 2 * idx_end).w0 & P.m_mask;
     const u64 h = mix2m(mm, P.m_mask);
-    const u32 bucket = routing_id(P, h);  // Brisk.hpp:135-137, plus the extra routing bits
+    const u32 rbase = routing_base(P, h);  // Brisk.hpp:135-137, plus the extra routing bits of the hash
     // replace the minimizer by its hash (replace_slice, Kmers.cpp:149-159)
     const W4 hole = w4_shl(W4{P.m_mask, 0, 0, 0}, 2 * idx_end);
     S = w4_or(w4_andn(S, hole), w4_shl(W4{h, 0, 0, 0}, 2 * idx_end));
@@ -194,42 +203,60 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
     const u32 cut = idx_end + P.suff_reduc;
     const W4 lowm = w4_mask(2 * cut);
     const W4 C = w4_or(w4_andn(w4_shr(S, 2 * P.b), lowm), w4_and(S, lowm));
+    const u32 idx_first = idx_end - (n - 1);
 
-    const u32 idx0p = idx_end - (n - 1) + P.suff_reduc;
-    u64* r;
-    if (out.bins) {
-        // One pass over the records instead of two: the histogram atomic every record pays anyway returns the record's
-        // rank in its partition, and the record goes straight to that slot of the partition's bin.  These random 32-byte
-        // stores ride along with a kernel that is bound by its vector instructions; k_scatter (209 M of the same stores and
-        // nothing else: 10-12 ms per 50 M reads) and the staging copy it read are gone.
-        const u32 part = bucket >> P.shift;
-        const u32 rank = (u32)atomicAdd(&out.hist[part], 1ull | ((unsigned long long)n << 32));
-        if (rank < out.bin_cap) {
-            r = out.bins + ((u64)part * out.bin_cap + rank) * P.stride;
-        } else {
-            const unsigned long long o = atomicAdd(out.n_ovf, 1ull);
-            if (o >= out.ovf_cap) {
-                *out.overflow = 1;
-                return;
-            }
-            r = out.ovf + o * P.stride;
+    // elements [j0, j1) of the vector share a routing id: all of them without classes
+    for (u32 j0 = 0; j0 < n;) {
+        u32 j1 = n, bucket = rbase;
+        if ((CLS ? P.cls_bits : 0u)) {
+            const u32 c = cls_of(P, idx_first + j0);
+            if (c + 1 < (1u << (CLS ? P.cls_bits : 0u))) j1 = min(n, (c + 1) * P.cls_width - idx_first);
+            bucket = (rbase << (CLS ? P.cls_bits : 0u)) | c;
         }
-    } else {
-        r = out.rec + slot * P.stride;
+        const u32 np = j1 - j0;
+        // the piece's compacted string: its last k-mer ends n - j1 nts before the vector's
+        W4 Cp = C;
+        if (np != n) Cp = w4_and(w4_shr(C, 2 * (n - j1)), w4_mask(2 * (P.kb + np - 1)));
+        u64* r;
+        if (out.bins) {
+            // One pass over the records instead of two: the histogram atomic every record pays anyway returns the record's
+            // rank in its partition, and the record goes straight to that slot of the partition's bin.  These random 32-byte
+            // stores ride along with a kernel that is bound by its vector instructions; k_scatter (209 M of the same stores and
+            // nothing else: 10-12 ms per 50 M reads) and the staging copy it read are gone.
+            const u32 part = bucket >> P.shift;
+            const u32 rank = (u32)atomicAdd(&out.hist[part], 1ull | ((unsigned long long)np << 32));
+            if (rank < out.bin_cap) {
+                r = out.bins + ((u64)part * out.bin_cap + rank) * P.stride;
+            } else {
+                const unsigned long long o = atomicAdd(out.n_ovf, 1ull);
+                if (o >= out.ovf_cap) {
+                    *out.overflow = 1;
+                    return;
+                }
+                r = out.ovf + o * P.stride;
+            }
+        } else {
+            r = out.rec + slot * P.stride;
+        }
+        r[0] = Cp.w0;
+        if (P.nw > 1) r[1] = Cp.w1;
+        if (P.nw > 2) r[2] = Cp.w2;
+        if (P.nw > 3) r[3] = Cp.w3;
+        r[P.nw] = rec_header(bucket, np, idx_first + j0 + P.suff_reduc);
+        if (!out.bins) {
+            if (out.tag) out.tag[slot] = tag;
+            if (out.ret) out.ret[slot] = ret;
+            if (out.hist) atomicAdd(&out.hist[bucket >> P.shift], 1ull | ((unsigned long long)np << 32));
+        }
+        slot++;
+        j0 = j1;
     }
-    r[0] = C.w0;
-    if (P.nw > 1) r[1] = C.w1;
-    if (P.nw > 2) r[2] = C.w2;
-    if (P.nw > 3) r[3] = C.w3;
-    r[P.nw] = rec_header(bucket, n, idx0p);
-    if (out.bins) return;
-    if (out.tag) out.tag[slot] = tag;
-    if (out.ret) out.ret[slot] = ret;
-    if (out.hist) atomicAdd(&out.hist[bucket >> P.shift], 1ull | ((unsigned long long)n << 32));
 }
 __device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
                             u32 idx_end, const ScanOut& out, u32 tag, u64 ret = 0) {
-    emit_record_at(P, packed, q0, p0, n, rev, idx_end, out, tag, ret, atomicAdd(out.n_rec, 1ull));
+    // (sequence mode, out.ret: the vectors go back to the caller as SuperKmerEnumerator::next yields them -- whole;
+    // BriskParams::cls_bits is 0 on the handles that serve it, brisk_hip_scan_sequence sees to that)
+    emit_record_at<true>(P, packed, q0, p0, n, rev, idx_end, out, tag, ret, atomicAdd(out.n_rec, (unsigned long long)superkmer_pieces<true>(P, n, idx_end)));
 }
 
 // query_mode: stop after the first super-k-mer whose returned minimizer is 0,
@@ -574,18 +601,61 @@ __device__ __forceinline__ void resolve_ties(u32 first, u32 last, bool rev_first
 // Emit queue entry (one u64 per closed super-k-mer): low word = the step (k-mer index in the lane's read) of its first
 // k-mer; high word = n | idx_end << 8 | reversed << 16 | (returned minimizer == 0) << 17 | lane << 18.  The lane's read
 // (stream index of its first nt, and its tag) is looked up in the wave's s_q0 / s_tag when the record is built.
+template <bool CLS>
 __device__ __forceinline__ void emit_queued(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, u64 ent, const u64* s_q0, const u32* s_tag,
                                             unsigned long long slot) {
     const u32 mi = (u32)(ent >> 32), src = (mi >> 18) & 63u;
     const u64 q_start = s_q0[src] + (u32)ent;
-    emit_record_at(P, packed, q_start, 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, s_tag[src], q_start | ((u64)((mi >> 17) & 1) << 63), slot);
+    emit_record_at<CLS>(P, packed, q_start, 0, mi & 0xff, (mi >> 16) & 1, (mi >> 8) & 0xff, out, s_tag[src], q_start | ((u64)((mi >> 17) & 1) << 63), slot);
+}
+
+// records the wave's queued super-k-mers become
+template <bool CLS>
+__device__ __forceinline__ u32 queue_records(const BriskParams& P, const u64* q_ent, u32 qcount) {
+    if (!(CLS ? P.cls_bits : 0u)) return qcount;
+    u32 mine = 0;
+    for (u32 e = threadIdx.x & 63; e < qcount; e += 64) {
+        const u32 mi = (u32)(q_ent[e] >> 32);
+        mine += superkmer_pieces<CLS>(P, mi & 0xff, (mi >> 8) & 0xff);
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    return mine;
+}
+// the queue's records into slots [base, base + queue_records())
+template <bool CLS>
+__device__ __forceinline__ void emit_queue(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, const u64* q_ent, const u64* s_q0, const u32* s_tag,
+                                           u32 qcount, unsigned long long base) {
+    const u32 lane = threadIdx.x & 63;
+    if (!(CLS ? P.cls_bits : 0u)) {
+        for (u32 e = lane; e < qcount; e += 64) emit_queued<CLS>(P, packed, out, q_ent[e], s_q0, s_tag, base + e);
+        return;
+    }
+    for (u32 e0 = 0; e0 < qcount; e0 += 64) {  // wave-uniform: the slots of 64 entries from an inclusive scan of their piece counts
+        const u32 e = e0 + lane;
+        u64 ent = 0;
+        u32 np = 0;
+        if (e < qcount) {
+            ent = q_ent[e];
+            const u32 mi = (u32)(ent >> 32);
+            np = superkmer_pieces<CLS>(P, mi & 0xff, (mi >> 8) & 0xff);
+        }
+        u32 incl = np;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 y = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += y;
+        }
+        if (e < qcount) emit_queued<CLS>(P, packed, out, ent, s_q0, s_tag, base + incl - np);
+        base += (u32)__shfl(incl, 63, 64);
+    }
 }
 
 // what is left in the waves' queues when their reads end: one slot reservation for the whole block
+template <bool CLS>
 __device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32* __restrict__ packed, const ScanOut& out, const u64* q_ent, const u64* s_q0,
                                                  const u32* s_tag, u32 qcount, u32* s_wcnt, unsigned long long* s_wbase) {
     const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) s_wcnt[wid] = qcount;
+    const u32 n_mine = queue_records<CLS>(P, q_ent, qcount);
+    if (lane == 0) s_wcnt[wid] = n_mine;
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 total = 0;
@@ -595,7 +665,7 @@ __device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32
     __syncthreads();
     unsigned long long base = *s_wbase;
     for (u32 i = 0; i < wid; i++) base += s_wcnt[i];
-    for (u32 e = lane; e < qcount; e += 64) emit_queued(P, packed, out, q_ent[e], s_q0, s_tag, base + e);
+    emit_queue<CLS>(P, packed, out, q_ent, s_q0, s_tag, qcount, base);
 }
 
 // minimum of x over the lane's 16-lane row, in every lane of the row (DPP row rotations: one instruction per step)
@@ -620,6 +690,7 @@ template <int NCH, int MODE, int KK, int MM>
 __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
                                                 u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, ChunkCtl cc) {
     constexpr bool VR = MODE == 2, query_mode = MODE == 1;
+    constexpr bool CLS = MM < 12;  // minimizer_idx classes in the routing id exist only where 2m < 24 (brisk_hip_create)
     extern __shared__ double smem_d[];
     const double* s_coef = smem_d;                        // 128
     const u64* s_tabs = (const u64*)(smem_d + 128);       // nch*256 packed fixed-point chunk sums
@@ -668,7 +739,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         max_nk = y > max_nk ? y : max_nk;
     }
     if (max_nk == 0) {  // nothing to scan in this wave; it still takes part in the block's final reservation
-        scan_final_flush(P, packed, out, q_ent, s_q0, s_tag, 0, s_wcnt, s_wbase);
+        scan_final_flush<CLS>(P, packed, out, q_ent, s_q0, s_tag, 0, s_wcnt, s_wbase);
         return;
     }
     const u64 KEY0 = order_key_fast<NCH>(0, m, M, nch, s_tabs, s_coef);
@@ -865,10 +936,11 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         // turn queued super-k-mers into records with full waves.  All waves append to one record counter, and
         // same-address atomics serialise device-wide (~15 ns each): one reservation per flush, not per record
         if (qcount + 64 > cfg.qcap) {
+            const u32 n_out = queue_records<CLS>(P, q_ent, qcount);
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)qcount);
+            if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)n_out);
             base = read_lane_u64(base, 0);
-            for (u32 e = lane; e < qcount; e += 64) emit_queued(P, packed, out, q_ent[e], s_q0, s_tag, base + e);
+            emit_queue<CLS>(P, packed, out, q_ent, s_q0, s_tag, qcount, base);
             qcount = 0;
         }
     }
@@ -886,5 +958,5 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         }
         qcount += (u32)__popcll(bal);
     }
-    scan_final_flush(P, packed, out, q_ent, s_q0, s_tag, qcount, s_wcnt, s_wbase);
+    scan_final_flush<CLS>(P, packed, out, q_ent, s_q0, s_tag, qcount, s_wcnt, s_wbase);
 }

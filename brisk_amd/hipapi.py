@@ -99,7 +99,7 @@ class _Options(C.Structure):
 
 class _Layout(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("k", "m", "b", "m_reduc", "compacted_size", "allocated_bytes", "record_words",
-                                          "part_bits", "n_owners", "owner_rank", "ext_bits")]
+                                          "part_bits", "n_owners", "owner_rank", "ext_bits", "cls_bits", "cls_width")]
 
 
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")

@@ -127,8 +127,13 @@ typedef struct brisk_hip_layout {
     uint32_t record_words;      /* u64 words per super-k-mer record (incl. header word) */
     uint32_t part_bits;         /* log2(#partitions) */
     uint32_t n_owners, owner_rank;
-    uint32_t ext_bits;          /* a record's routing id (header bits 0..31) = bucket id << ext_bits | that many more bits of
-                                 * the same hashed minimizer; 0 when 2b >= 24 or part_bits was given: the bucket id itself */
+    uint32_t ext_bits;          /* a record's routing id (header bits 0..31) = bucket id << ext_bits | ext_bits more bits: first
+                                 * more of the same hashed minimizer, then (lowest) cls_bits of class; 0 when 2b >= 24 or
+                                 * part_bits was given: the bucket id itself */
+    uint32_t cls_bits;          /* 2m < 24 only: the lowest cls_bits of a routing id are min(minimizer_idx / cls_width,
+                                 * 2^cls_bits - 1) of the record's k-mers, and a super-k-mer spanning several classes is
+                                 * scanned into one record per class (each a valid super-k-mer of the same bucket) */
+    uint32_t cls_width;
 } brisk_hip_layout;
 int brisk_hip_get_layout(const brisk_hip_index *h, brisk_hip_layout *out);
 
