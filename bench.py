@@ -113,8 +113,9 @@ def main():
 
     # one handle for the whole run: every step starts from brisk_hip_clear(), i.e. an
     # empty index whose device memory is already reserved (the allocator, not the path)
-    from brisk_amd.exchange import ShardedCounter
-    sc = ShardedCounter(k, m, b, rank, N, dev_index, stream, part_bits=args.part_bits)
+    from brisk_amd.exchange import ShardedCounter, suggest_part_bits
+    part_bits = args.part_bits or (suggest_part_bits(b, total_reads) if N > 1 else 0)
+    sc = ShardedCounter(k, m, b, rank, N, dev_index, stream, part_bits=part_bits)
     ix = sc.ix
 
     def one_job(profile):
@@ -192,7 +193,7 @@ def main():
             "config": {"workload": "%dx MI355X: %s synthetic %d bp reads %s, k=%d m=%d b=%d, uint8 counts, %gx coverage"
                                    % (N, ("%dM" % (args.reads // 1_000_000)) if args.reads >= 1_000_000 else str(args.reads), L,
                                       "per GPU" if args.scaling == "weak" else "in all", k, m, b, args.coverage),
-                       "reads_per_gpu": n_reads, "total_reads": total_reads, "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
+                       "reads_per_gpu": n_reads, "total_reads": total_reads, "part_bits": ix.layout["part_bits"], "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
                        "parallelism": "bucket-range shard x%d + all-to-all" % N if N > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

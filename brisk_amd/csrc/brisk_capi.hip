@@ -397,13 +397,34 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
 }
 
 // exclusive prefix of the record histogram -> d_off (n_parts+1), d_cur32 seeded
-int prefix_partitions(brisk_hip_index* h, u64 n_bins, u32 sub = 0) {  // sub: over the records beyond `sub` per partition
+// The partitions an index can hold records of: all of them, or its owner's range of a sharded job.  Everything that walks the
+// partitions of a batch (prefix sums, the touched list) walks this range only: with N owners the directory has N times the
+// partitions a single index needs, and each owner sees records in one N-th of them.
+struct PartRange {
+    u64 lo, len;
+};
+// first partition of owner o's range: the smallest p with p * N >> part_bits == o
+static u64 owner_first_partition(const BriskParams& P, u32 o) { return (((u64)o << P.part_bits) + P.n_owners - 1) / P.n_owners; }
+static PartRange own_partitions(const brisk_hip_index* h) {
+    if (h->P.n_owners <= 1) return PartRange{0, h->n_parts};
+    const u64 lo = owner_first_partition(h->P, h->P.owner_rank);
+    return PartRange{lo, owner_first_partition(h->P, h->P.owner_rank + 1) - lo};
+}
+// exclusive prefix of the histogram's record counts over the index's own partitions -> d_off, d_cur32 (d_off[lo + len] = total)
+int prefix_partitions(brisk_hip_index* h, u32 sub = 0) {  // sub: over the records beyond `sub` per partition
     ProfScope ps(h, S_PSUM);
-    const u32 nb = nblocks(n_bins, 256 * SCAN_ITEMS);
-    hipLaunchKernelGGL(k_psum_block, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums, sub);
+    const PartRange r = own_partitions(h);
+    const u32 nb = nblocks(r.len, 256 * SCAN_ITEMS);
+    hipLaunchKernelGGL(k_psum_block, dim3(nb), dim3(256), 0, h->stream, h->d_hist + r.lo, r.len, h->d_block_sums, sub);
     hipLaunchKernelGGL(k_psum_top, dim3(1), dim3(1024), 0, h->stream, h->d_block_sums, nb);
-    hipLaunchKernelGGL(k_psum_apply, dim3(nb), dim3(256), 0, h->stream, h->d_hist, n_bins, h->d_block_sums, h->d_off, h->d_cur32, sub);
+    hipLaunchKernelGGL(k_psum_apply, dim3(nb), dim3(256), 0, h->stream, h->d_hist + r.lo, r.len, h->d_block_sums, h->d_off + r.lo, h->d_cur32 + r.lo, sub);
     return launch_check(h, "prefix_partitions");
+}
+// the own partitions that hold records of this batch -> d_touched, their number -> *d_n
+int list_touched(brisk_hip_index* h, u32* d_n) {
+    const PartRange r = own_partitions(h);
+    hipLaunchKernelGGL(k_touched, dim3(nblocks(r.len, 1024 * TOUCHED_ITEMS)), dim3(1024), 0, h->stream, h->d_hist + r.lo, r.len, (u32)r.lo, h->d_touched, d_n);
+    return launch_check(h, "k_touched");
 }
 
 // records (unordered, all owned by this index) -> index.  If have_hist, d_hist
@@ -442,13 +463,20 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     }
     // classic layout: all records go to partition order; binned layout: only the few beyond their bins do
     const u64 n_move = bl ? bl->n_ovf : n_rec;
-    if (n_move && (rc = prefix_partitions(h, h->n_parts, bl ? bl->bin_cap : 0u))) return rc;
+    if (n_move && (rc = prefix_partitions(h, bl ? bl->bin_cap : 0u))) return rc;
+    if (P.n_owners > 1 && !have_hist) {
+        // records counted here, not by their scan: every one of them must lie in this owner's range (the prefix ran over it alone,
+        // and a record of another owner would be scattered by a cursor nobody set)
+        const PartRange r = own_partitions(h);
+        u32 in_range = 0;
+        HIPCHK(h, hipMemcpyAsync(&in_range, h->d_off + r.lo + r.len, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (in_range != n_rec) return fail(h, BRISK_HIP_EINVAL, "insert_records: " + std::to_string(n_rec - in_range) + " records belong to other owners (route_records first)");
+    }
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 16, h->stream));
     {
         ProfScope ps(h, S_TOUCHED);
-        hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 1024 * TOUCHED_ITEMS)), dim3(1024), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
-                           (u32*)(h->d_small + 2));
-        if (int lrc = launch_check(h, "k_touched")) return lrc;
+        if ((rc = list_touched(h, (u32*)(h->d_small + 2)))) return rc;
     }
     if (n_move) {
         if ((rc = ensure(h, h->parted, n_move * P.stride * 8))) return rc;
@@ -520,6 +548,9 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     }
         static const bool generic_only = getenv("BRISK_INSERT_GENERIC") != nullptr;  // A/B and tests: force the run-time body
         if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_INSERT_FAST(3, 49, 4)        // k63 m21 b14
+        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 3) LAUNCH_INSERT_FAST(3, 49, 3)  // the same with 2^25..2^27 partitions:
+        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_INSERT_FAST(3, 49, 2)  // jobs of 2..8 x 50 M reads per batch over
+        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_INSERT_FAST(3, 49, 1)  // as many owners (brisk_hip_options.part_bits)
         else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_INSERT_FAST(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
         else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_INSERT_FAST(2, 20, 0)  // k31 m11 b11
         else LAUNCH_INSERT(0, 0, 0)
@@ -867,11 +898,9 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
     const BriskParams& P = h->P;
     h->scan_hist_valid = false;
     int rc;
-    if ((rc = prefix_partitions(h, h->n_parts))) return rc;
+    if ((rc = prefix_partitions(h))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
-    hipLaunchKernelGGL(k_touched, dim3(nblocks(h->n_parts, 1024 * TOUCHED_ITEMS)), dim3(1024), 0, h->stream, h->d_hist, h->n_parts, h->d_touched,
-                       (u32*)(h->d_small + 2));
-    if (int lrc = launch_check(h, "k_touched")) return lrc;
+    if ((rc = list_touched(h, (u32*)(h->d_small + 2)))) return rc;
     if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
     if ((rc = ensure(h, h->tags_b, n_rec * 4))) return rc;
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_cur32,
@@ -1442,7 +1471,7 @@ static int enumerate_impl(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo
     HIPCHK(h, hipMemcpyAsync(d_base, base.data(), np * 8, hipMemcpyHostToDevice, h->stream));
     if (total) {
         ProfScope ps(h, S_ENUM);
-        hipLaunchKernelGGL(k_enumerate, dim3((u32)np), dim3(64), 0, h->stream, h->P, h->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt, d_ids);
+        hipLaunchKernelGGL(k_enumerate, dim3((u32)std::min<u64>(np, 1u << 22)), dim3(64), 0, h->stream, h->P, h->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt, d_ids);
         if ((rc = launch_check(h, "k_enumerate"))) return rc;
         HIPCHK(h, hipMemcpyAsync(out_lo, d_lo, total * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(out_hi, d_hi, total * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1554,7 +1583,7 @@ BRISK_API int brisk_hip_reallocate(brisk_hip_index* from, brisk_hip_index* to) {
         uint8_t* d_idx = (uint8_t*)(d_hi + total) + total * 4;
         uint8_t* d_cnt = d_idx + total;
         HIPCHK(h, hipMemcpyAsync(d_base, base.data(), np * 8, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_enumerate, dim3((u32)np), dim3(64), 0, h->stream, from->P, from->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt, (u32*)nullptr);
+        hipLaunchKernelGGL(k_enumerate, dim3((u32)std::min<u64>(np, 1u << 22)), dim3(64), 0, h->stream, from->P, from->ix, (u32)p, (u32)np, d_base, d_lo, d_hi, d_idx, d_cnt, (u32*)nullptr);
         if ((rc = launch_check(h, "k_enumerate"))) return rc;
         HIPCHK(h, hipMemsetAsync((char*)h->packed_tmp.p + n_words * 4, 0, 16, h->stream));
         hipLaunchKernelGGL(k_kmers_to_reads, dim3(nblocks(std::max<u64>(n_words, total + 1), 256)), dim3(256), 0, h->stream, d_lo, d_hi, total, k, (u32*)h->packed_tmp.p,
@@ -1647,15 +1676,25 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     return rc;
 }
 
-// first partition of owner o's range: the smallest p with p * N >> part_bits == o
-static u64 owner_first_partition(const BriskParams& P, u32 o) { return (((u64)o << P.part_bits) + P.n_owners - 1) / P.n_owners; }
-
 BRISK_API int brisk_hip_export_hist(brisk_hip_index* h, uint64_t* d_hist_out, uint64_t* partitions_per_owner) {
     if (!h || !d_hist_out || !partitions_per_owner) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
     HIPCHK(h, hipMemcpyAsync(d_hist_out, h->d_hist, h->n_parts * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h->P, o + 1) - owner_first_partition(h->P, o);
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_export_hist_add(brisk_hip_index* h, uint64_t* d_hist_acc, uint64_t* partitions_per_owner) {
+    if (!h || !d_hist_acc || !partitions_per_owner) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist_add: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
+    hipLaunchKernelGGL(k_add_u64, dim3(std::min<u32>(nblocks(h->n_parts, 1024), 8192)), dim3(256), 0, h->stream, (const unsigned long long*)h->d_hist, h->n_parts,
+                       (unsigned long long*)d_hist_acc);
+    if (int lrc = launch_check(h, "k_add_u64")) return lrc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h->P, o + 1) - owner_first_partition(h->P, o);
     return BRISK_HIP_OK;

@@ -81,10 +81,26 @@ __global__ void __launch_bounds__(256) k_psum_apply(const unsigned long long* __
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) off[n] = run;  // total
 }
 
+// acc[i] += v[i] (both counters of a histogram word at once: neither carries into the other before 2^32 records)
+__global__ void __launch_bounds__(256) k_add_u64(const unsigned long long* __restrict__ v, u64 n, unsigned long long* __restrict__ acc) {
+    for (u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (u64)gridDim.x * 512) {
+        if (i + 1 < n) {
+            const ulonglong2 a = *(const ulonglong2*)(v + i);
+            ulonglong2 b = *(ulonglong2*)(acc + i);
+            b.x += a.x;
+            b.y += a.y;
+            *(ulonglong2*)(acc + i) = b;
+        } else {
+            acc[i] += v[i];
+        }
+    }
+}
+
 // list of partitions with records, ascending inside a block.  One list-cursor atomic per block of 8192
 // partitions: every same-address atomic costs ~15 ns device-wide, whoever issues it.
 #define TOUCHED_ITEMS 8
-__global__ void __launch_bounds__(1024) k_touched(const unsigned long long* __restrict__ hist, u64 n, u32* __restrict__ list, u32* __restrict__ n_list) {
+// (hist, n: the index's own partitions, the first of them partition `first`)
+__global__ void __launch_bounds__(1024) k_touched(const unsigned long long* __restrict__ hist, u64 n, u32 first, u32* __restrict__ list, u32* __restrict__ n_list) {
     __shared__ u32 s_wsum[16];
     __shared__ u32 s_base;
     const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -114,7 +130,7 @@ __global__ void __launch_bounds__(1024) k_touched(const unsigned long long* __re
     u32 at = s_base + s_wsum[wid] + incl - cnt;
 #pragma unroll
     for (u32 j = 0; j < TOUCHED_ITEMS; j++)
-        if (mask >> j & 1) list[at++] = (u32)(p0 + j);
+        if (mask >> j & 1) list[at++] = first + (u32)(p0 + j);
 }
 
 // Per touched partition: a 32-byte work descriptor for k_insert (so that its

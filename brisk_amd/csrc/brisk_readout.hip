@@ -137,25 +137,26 @@ __global__ void __launch_bounds__(256) k_dir_counts(const DirEnt* __restrict__ d
 __global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u32 p_begin, u32 n_parts, const u64* __restrict__ out_base,
                                                   u64* __restrict__ out_lo, u64* __restrict__ out_hi, uint8_t* __restrict__ out_idx,
                                                   uint8_t* __restrict__ out_cnt, u32* __restrict__ out_id) {
-    const u32 pi = blockIdx.x;
-    if (pi >= n_parts) return;
-    const u32 part = p_begin + pi;
-    const u32 cnt = ix.dir[part].cnt;
-    const unsigned long long off = ix.dir[part].off;
-    const u64 ob = out_base[pi];
-    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
-        u32 idx;
-        u128x hk = entry_hashed_kmer(P, part, key, &idx);
-        // unhash_kmer_minimizer (Kmers.cpp:178-187)
-        const u64 hm = shr128(hk, 2 * idx).lo & P.m_mask;
-        const u64 mm = mix2m_inv(hm, P.m_mask);
-        hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
-        out_lo[ob + e] = hk.lo;
-        out_hi[ob + e] = hk.hi;
-        out_idx[ob + e] = (uint8_t)idx;
-        out_cnt[ob + e] = ix.counts[off + e];
-        if (out_id) out_id[ob + e] = ix.ids[off + e];
+    for (u32 pi = blockIdx.x; pi < n_parts; pi += gridDim.x) {  // (a chunk of a sparse index spans up to 2^27 partitions: more than a grid of 64-lane blocks may have)
+        const u32 part = p_begin + pi;
+        const u32 cnt = ix.dir[part].cnt;
+        if (!cnt) continue;
+        const unsigned long long off = ix.dir[part].off;
+        const u64 ob = out_base[pi];
+        for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+            u32 idx;
+            u128x hk = entry_hashed_kmer(P, part, key, &idx);
+            // unhash_kmer_minimizer (Kmers.cpp:178-187)
+            const u64 hm = shr128(hk, 2 * idx).lo & P.m_mask;
+            const u64 mm = mix2m_inv(hm, P.m_mask);
+            hk = or128(andn128(hk, shl128(mk128(P.m_mask, 0), 2 * idx)), shl128(mk128(mm, 0), 2 * idx));
+            out_lo[ob + e] = hk.lo;
+            out_hi[ob + e] = hk.hi;
+            out_idx[ob + e] = (uint8_t)idx;
+            out_cnt[ob + e] = ix.counts[off + e];
+            if (out_id) out_id[ob + e] = ix.ids[off + e];
+        }
     }
 }
 

@@ -108,6 +108,21 @@ def agree_pieces(n_reads: int, device, group=None, four_from: int = 1 << 22) -> 
     return 4 if most >= four_from else (2 if most >= 2 else 1)
 
 
+def suggest_part_bits(b: int, reads_per_batch: int) -> int:
+    """log2(#partitions) for a sharded job whose ranks together count `reads_per_batch` reads per count_packed call
+    (0: the library default, 2^24).  The insert wants 10-20 records per partition and call (include/brisk_hip.h,
+    brisk_hip_options.part_bits): 50 M reads bring 209 M records, 12 per partition at 2^24.  N owners that each receive
+    that much (N x 50 M reads per batch) keep the same density with N times the partitions -- each still walks only its
+    own N-th of them; with 2^24 for 400 M reads the partitions hold 100 records each and the insert takes 2.5x as long
+    (77 against 31 ms per owner and batch, tools/owner_emulation.py on one MI355X).  Explicit partition counts are bucket ranges:
+    at most 2b bits."""
+    import math
+    if reads_per_batch <= 0:
+        return 0
+    bits = min(int(round(math.log2(max(reads_per_batch, 3) / 3.0))), 2 * b)
+    return bits if bits > 24 else 0
+
+
 class ShardedCounter:
     """A rank's share of a k-mer counting job: owns the buckets of its partition range."""
 
@@ -119,7 +134,7 @@ class ShardedCounter:
         self.ix = brisk_amd.BriskHip(k, m, b, device=device, stream=stream.cuda_stream, owner_rank=rank, n_owners=world,
                                      part_bits=part_bits)
         self.W = self.ix.record_words
-        self._rec = self._out = self._inbox = self._hist = None
+        self._rec = self._out = self._inbox = self._hist = self._slices = None
         self._cap = 0
 
     # reads per rank from which a batch goes in four pieces (patchable: the tests lower it)
@@ -151,10 +166,12 @@ class ShardedCounter:
                 self._rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
                 self._out = [torch.empty(cap * W, dtype=torch.int64, device=self.dev) for _ in halves]
                 self._inbox = torch.empty(len(halves) * (cap + cap // 4) * W, dtype=torch.int64, device=self.dev)
-            if self._hist is None or len(self._hist) != len(halves):
-                self._hist = [torch.empty(n_parts, dtype=torch.int64, device=self.dev) for _ in halves]
-            slices = None
-            works, n_in_total, n_slices = [], 0, 0
+            # the scan's per-partition counts of ALL pieces, summed here: one slice per owner travels per batch
+            if self._hist is None:
+                self._hist = torch.empty(n_parts, dtype=torch.int64, device=self.dev)
+            self._hist.zero_()
+            lens = None
+            works, n_in_total = [], 0
             for hi_, (lo, hi) in enumerate(halves):
                 starts_ptr = d_starts.data_ptr() + lo * 8
                 while True:
@@ -179,7 +196,7 @@ class ShardedCounter:
                 counts = ix.route_records(self._rec.data_ptr(), n_rec, out.data_ptr())
                 # the scan counted its records per partition: each owner gets the slice of its range and adds the
                 # slices up instead of counting the records it receives again (209 M random atomics per 50 M reads)
-                lens = [int(v) for v in ix.export_hist(self._hist[hi_].data_ptr())]
+                lens = [int(v) for v in ix.export_hist_add(self._hist.data_ptr())]
                 recv_counts = exchange_counts(counts, self.dev, self.group)
                 n_in = sum(recv_counts)
                 if (n_in_total + n_in) * W > self._inbox.numel():  # skewed ownership: make room (what arrived is kept)
@@ -192,12 +209,12 @@ class ShardedCounter:
                     bigger[: n_in_total * W].copy_(self._inbox[: n_in_total * W])
                     self._inbox = bigger
                 works.append(exchange_payload_async(out, counts, recv_counts, W, self._inbox, n_in_total, self.group))
-                my_len = lens[self.rank]
-                if slices is None:
-                    slices = torch.empty(len(halves) * self.world * my_len, dtype=torch.int64, device=self.dev)
-                works.append(exchange_payload_async(self._hist[hi_], lens, [my_len] * self.world, 1, slices, n_slices * my_len, self.group))
                 n_in_total += n_in
-                n_slices += self.world
+            my_len = lens[self.rank]
+            if self._slices is None or self._slices.numel() != self.world * my_len:
+                self._slices = torch.empty(self.world * my_len, dtype=torch.int64, device=self.dev)
+            slices, n_slices = self._slices, self.world
+            works.append(exchange_payload_async(self._hist, lens, [my_len] * self.world, 1, slices, 0, self.group))
             self._cap = cap
             for w in works:
                 if w is not None:

@@ -110,7 +110,7 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_reallocate", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
+    "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_export_hist_add", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
@@ -149,6 +149,7 @@ def load() -> C.CDLL:
     L.brisk_hip_route_records.argtypes = [vp, vp, u64, vp, _u64p]
     L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
     L.brisk_hip_export_hist.argtypes = [vp, vp, _u64p]
+    L.brisk_hip_export_hist_add.argtypes = [vp, vp, _u64p]
     L.brisk_hip_insert_records_hist.argtypes = [vp, vp, u64, vp, u32]
     L.brisk_hip_scan_query.argtypes = [vp, vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.brisk_hip_route_tagged.argtypes = [vp, vp, vp, u64, vp, vp, _u64p]
@@ -346,6 +347,12 @@ class BriskHip:
         """copy the last scan's per-partition histogram (2^part_bits u64) to d_hist_out; returns the slice length per owner"""
         lens = np.zeros(max(self.layout["n_owners"], 1), np.uint64)
         self._chk(self.L.brisk_hip_export_hist(self.h, d_hist_out, lens))
+        return lens
+
+    def export_hist_add(self, d_hist_acc: int) -> np.ndarray:
+        """add the last scan's per-partition histogram to d_hist_acc (2^part_bits u64); returns the slice length per owner"""
+        lens = np.zeros(max(self.layout["n_owners"], 1), np.uint64)
+        self._chk(self.L.brisk_hip_export_hist_add(self.h, d_hist_acc, lens))
         return lens
 
     def insert_records_hist(self, d_records: int, n: int, d_hist_slices: int, n_slices: int):

@@ -97,7 +97,10 @@ typedef struct brisk_hip_options {
     uint32_t struct_size;       /* sizeof(brisk_hip_options), for ABI growth */
     int32_t device;             /* HIP device ordinal */
     void *stream;               /* hipStream_t to run on, NULL: the library creates one */
-    uint32_t part_bits;         /* log2(#partitions); 0: default min(2b, 24) */
+    uint32_t part_bits;         /* log2(#partitions), at most 2b; 0: default (2^24, also when 2b < 24: see brisk_hip_layout.ext_bits).
+                                 * The insert is at its best with 10-20 records (a few hundred k-mer instances) per partition
+                                 * and call: 2^24 suits batches of 50 M reads on one index; a sharded job whose owners each
+                                 * receive that much (N x 50 M reads per batch over N owners) wants 24 + log2(N) */
     uint32_t owner_rank;        /* this process' rank among n_owners bucket-range owners */
     uint32_t n_owners;          /* 0 or 1: this index owns every bucket; at most 256 (else EUNSUPPORTED) */
     uint64_t arena_entries;     /* initial entry capacity of the k-mer arena; 0: grow on demand */
@@ -214,8 +217,11 @@ int brisk_hip_insert_records(brisk_hip_index *h, const uint64_t *d_records, uint
  * (HOST) receives the length of each owner's slice, so that the slices can travel with the records.
  * insert_records_hist is insert_records for an owner that received one such slice of ITS range from
  * each scanning rank (n_slices slices of equal length, back to back): it adds them up instead of
- * counting the received records again. */
+ * counting the received records again.  export_hist_add ADDS the histogram to d_hist_acc (2^part_bits u64 the
+ * caller zeroed) instead: a rank that scans its reads in several pieces sends one summed slice per owner per
+ * batch, not one per piece. */
 int brisk_hip_export_hist(brisk_hip_index *h, uint64_t *d_hist_out, uint64_t *partitions_per_owner);
+int brisk_hip_export_hist_add(brisk_hip_index *h, uint64_t *d_hist_acc, uint64_t *partitions_per_owner);
 int brisk_hip_insert_records_hist(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records,
                                   const uint64_t *d_hist_slices, uint32_t n_slices);
 /* The query path cut at the same boundary.  scan_query = the scan as query_sequence runs it (a read's

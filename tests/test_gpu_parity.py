@@ -267,6 +267,78 @@ def test_bucket_range_sharding_two_owners(B, O):
         assert (sorted(lines), nk, nb) == want
 
 
+def test_sharding_with_more_partitions_and_summed_histograms(B, O):
+    """A sharded job sized for N x the reads (include/brisk_hip.h, brisk_hip_options.part_bits): 2^25 and 2^27 partitions
+    over 2 and 3 owners, each rank scanning its reads in two pieces whose histograms are summed before they travel
+    (brisk_hip_export_hist_add).  Union of the shards == oracle; records of another owner are refused."""
+    import torch
+    rng = random.Random(47)
+    reads = _random_reads(rng, 900, 6000) + SPECIAL
+    k, m, b = 63, 21, 14
+    want = O.count(reads, k, m, b)
+    flat, offs = oracle.pack_reads(reads)
+    d_bases = torch.from_numpy(flat).cuda()
+    d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+    for n_owners, part_bits in ((2, 25), (3, 27)):
+        owners = [B.BriskHip(k, m, b, owner_rank=r, n_owners=n_owners, part_bits=part_bits) for r in range(n_owners)]
+        assert owners[0].layout["part_bits"] == part_bits
+        torch.cuda.synchronize()
+        owners[0].pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        owners[0].sync()
+        W = owners[0].record_words
+        n_parts = 1 << part_bits
+        inbox = [[] for _ in range(n_owners)]
+        slices = [[] for _ in range(n_owners)]
+        share = [len(reads) * i // n_owners for i in range(n_owners + 1)]
+        for r in range(n_owners):  # rank r scans its share in two pieces
+            ix = owners[r]
+            acc = torch.zeros(n_parts, dtype=torch.int64, device="cuda")
+            mid = (share[r] + share[r + 1]) // 2
+            for lo, hi in ((share[r], mid), (mid, share[r + 1])):
+                st = d_starts[lo:hi + 1].contiguous()
+                bound = ix.scan_bound(st.data_ptr(), hi - lo)
+                d_rec = torch.zeros(max(bound, 1) * W, dtype=torch.int64, device="cuda")
+                d_out = torch.zeros_like(d_rec)
+                torch.cuda.synchronize()
+                n_rec = ix.scan_packed(d_packed.data_ptr(), st.data_ptr(), hi - lo, d_rec.data_ptr(), bound)
+                counts = ix.route_records(d_rec.data_ptr(), n_rec, d_out.data_ptr())
+                lens = ix.export_hist_add(acc.data_ptr())
+                ix.sync()
+                assert int(counts.sum()) == n_rec and int(lens.sum()) == n_parts
+                at = 0
+                for o in range(n_owners):
+                    inbox[o].append(d_out[at * W:(at + int(counts[o])) * W].clone())
+                    at += int(counts[o])
+            assert int((acc & 0xffffffff).sum()) == sum(t.numel() // W for o in range(n_owners) for t in inbox[o][2 * r:])
+            at = 0
+            for o in range(n_owners):
+                slices[o].append(acc[at:at + int(lens[o])].clone())
+                at += int(lens[o])
+        lines, nk, nb = [], 0, 0
+        for r in range(n_owners):
+            recv = torch.cat(inbox[r])
+            sl = torch.cat(slices[r])
+            torch.cuda.synchronize()
+            if r == 0 and n_owners == 2:
+                # what belongs to the other owner is not taken: nothing is inserted, the index stays usable
+                foreign = torch.cat(inbox[1])
+                with pytest.raises(B.BriskHipError) as e:
+                    owners[0].insert_records(foreign.data_ptr(), foreign.numel() // W)
+                assert e.value.code == 1 and "other owners" in str(e.value)  # EINVAL
+                owners[0].insert_records(recv.data_ptr(), recv.numel() // W)  # counted here
+            else:
+                owners[r].insert_records_hist(recv.data_ptr(), recv.numel() // W, sl.data_ptr(), n_owners)
+            owners[r].sync()
+            st = owners[r].stats()
+            nk += st["nb_kmers"]
+            nb += st["nb_buckets"]
+            lines += oracle.multiset_lines(*owners[r].enumerate(), k)
+        for ix in owners:
+            ix.close()
+        assert (sorted(lines), nk, nb) == want
+
+
 def test_get_across_two_owners(B, O):
     """sharded get: scan_query -> route_tagged -> (exchange) -> query_records on the owner -> sums back ->
     per-read sums == the oracle's query of the whole index (incl. the minimizer==0 break, poly-A reads)"""

@@ -203,3 +203,15 @@ def test_owner_of_bucket_takes_the_routing_id():
     assert owner_of_bucket(rid >> 16, 4, 8, 2).tolist() == [0, 0, 1, 1]  # explicit part_bits: plain bucket ranges
     with pytest.raises(ValueError):
         owner_of_bucket(rid, 4, 24, 2)
+
+
+def test_partition_count_follows_the_batch():
+    """brisk_hip_options.part_bits for sharded jobs: ~3 reads per partition and batch, never below the default, at most 2b"""
+    from brisk_amd.exchange import suggest_part_bits
+    assert suggest_part_bits(14, 50_000_000) == 0      # one GPU's batch: the library default (2^24)
+    assert suggest_part_bits(14, 100_000_000) == 25
+    assert suggest_part_bits(14, 200_000_000) == 26
+    assert suggest_part_bits(14, 400_000_000) == 27    # BASELINE config #4
+    assert suggest_part_bits(14, 10**10) == 28         # bucket ranges: at most 2b bits
+    assert suggest_part_bits(11, 400_000_000) == 0     # 2b = 22 < 24: nothing to scale
+    assert suggest_part_bits(14, 0) == 0
