@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -201,6 +202,12 @@ int main(int argc, char** argv) {
     o.stream = stream;
     o.owner_rank = (uint32_t)rank;
     o.n_owners = (uint32_t)world;
+    // about three reads of the batch per partition (include/brisk_hip.h, brisk_hip_options.part_bits; the same rule as
+    // brisk_amd/exchange.py, suggest_part_bits): beyond the default 2^24 only for jobs of more than ~70 M reads
+    if (world > 1) {
+        const uint32_t bits = std::min<uint32_t>((uint32_t)std::lround(std::log2((double)std::max<uint64_t>(total, 3) / 3.0)), 2u * b);
+        if (bits > 24) o.part_bits = bits;
+    }
     brisk_hip_index* h = nullptr;
     int rc = brisk_hip_create(&h, k, m, b, 1, dede.coef(), &o);
     if (rc != BRISK_HIP_OK) {

@@ -917,9 +917,27 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
     {
         ProfScope ps(h, S_QUERY);
         HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_query, dim3(std::min<u32>((n_touched + WI_BATCH - 1) / WI_BATCH, INSERT_SLOTS)), dim3(64), 0, h->stream, P,
-                           (const u64*)h->parted.p, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums,
-                           (u32*)(h->d_small + 6));
+        const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
+        auto resident = [&](const void* fn) -> u32 {  // persistent waves: as many as the device keeps resident
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
+            return std::min<u32>((u32)per_cu * (u32)cus, INSERT_SLOTS);
+        };
+#define LAUNCH_QUERY_FAST(NW, KB, SH)                                                                                                               \
+    hipLaunchKernelGGL((k_query_fast<NW, KB, SH>), dim3(std::min<u32>(batches, resident((const void*)k_query_fast<NW, KB, SH>))), dim3(64), 0, h->stream, P, \
+                       (const u64*)h->parted.p, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6))
+        static const bool generic_only = getenv("BRISK_QUERY_GENERIC") != nullptr;  // A/B and tests: force the run-time body
+        if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_QUERY_FAST(3, 49, 4);       // k63 m21 b14
+        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 3) LAUNCH_QUERY_FAST(3, 49, 3);  // (sharded, 2^25..2^27 partitions)
+        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_QUERY_FAST(3, 49, 2);
+        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_QUERY_FAST(3, 49, 1);
+        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_QUERY_FAST(2, 17, 4);  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_QUERY_FAST(2, 20, 0);  // k31 m11 b11
+        else
+            hipLaunchKernelGGL(k_query, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (const u64*)h->parted.p, (const u32*)h->tags_b.p,
+                               (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6));
+#undef LAUNCH_QUERY_FAST
     }
     return launch_check(h, "k_query");
 }
@@ -1400,6 +1418,21 @@ BRISK_API int brisk_hip_get_reads(brisk_hip_index* h, const char* bases, const u
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return BRISK_HIP_OK;
     });
+}
+
+BRISK_API int brisk_hip_get_packed(brisk_hip_index* h, const uint32_t* d_packed, const uint64_t* d_starts, uint64_t n_reads, uint64_t* d_per_read_sum) {
+    if (!h || (n_reads && (!d_packed || !d_starts || !d_per_read_sum))) return BRISK_HIP_EINVAL;
+    if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "get_packed on a sharded index sees one bucket range only: use scan_query / route_tagged / query_records");
+    if (!n_reads) return BRISK_HIP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    HIPCHK(h, hipMemsetAsync(d_per_read_sum, 0, n_reads * 8, h->stream));
+    for (u64 r0 = 0; r0 < n_reads; r0 += h->max_batch_reads) {  // the record tags of a batch are indices into its own slice of the sums
+        const u64 nb = std::min<u64>(h->max_batch_reads, n_reads - r0);
+        if (int rc = query_packed_impl(h, d_packed, d_starts + r0, nb, (unsigned long long*)d_per_read_sum + r0)) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return check_device_flags(h);
 }
 
 BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, const uint64_t* kmer_hi, const uint8_t* minimizer_idx, uint64_t n,

@@ -91,6 +91,146 @@ __global__ void __launch_bounds__(64) k_query(BriskParams P, const u64* __restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_query_fast: the query with the roles turned round and the record geometry as constants (the parameter sets k_insert_fast
+// has).  The table holds a chunk of the partition's ENTRIES -- distinct keys, so a probe chain ends at the first match and
+// building it needs no comparison -- and the k-mer instances of the partition's records, cut out of 32-bit record words as in
+// expand_and_dedupe_words, probe it straight from registers: no per-instance state in LDS, no chains of equal keys (k_query
+// parks every instance in a slot of its own, 3.4 equal keys behind each other at 15x coverage, and walks all of them for
+// every entry).  Same results: per record the sum of the counts of its k-mers that are present, one atomic per record into
+// its read's sum.
+#define QF_ENT 256u           // entries per table chunk
+#define QF_TABLE 512u
+#define QF_MAX_INST 768u      // instances per chunk of <= 64 records (the info word's prefix field has 10 bits)
+template <u32 NW, u32 KB, u32 SHIFT>
+__device__ __forceinline__ void inst_key_words(const u32* s_rw, u32 r, u32 i, u64* lo_out, u64* hi_out) {
+    constexpr u32 RS = RecGeom<NW>::RS, INFO = RecGeom<NW>::INFO, KBITS = 2 * KB + 6;
+    const u32* base = s_rw + r * RS;
+    const u32 info = base[INFO];
+    const u32 j = i - (info & 0x3ffu);
+    const u32 n = (info >> 10) & 0xffu;
+    const u32 s = 2 * (n - 1 - j);
+    const u32* wp = base + (s >> 5);
+    const u32 sh = s & 31;
+    const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
+    u32 k0 = __builtin_amdgcn_alignbit(w1, w0, sh), k1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+    u32 k2 = __builtin_amdgcn_alignbit(w3, w2, sh), k3 = __builtin_amdgcn_alignbit(w4, w3, sh);
+    k0 = (k0 & ~0x3fu) | (((info >> 18) & 0xffu) + j);  // idx' = idx0' + j (SuperKmerLight.hpp:98)
+    constexpr u32 m0 = KBITS >= 32 ? ~0u : (1u << KBITS) - 1, m1 = KBITS >= 64 ? ~0u : KBITS <= 32 ? 0u : (1u << (KBITS - 32)) - 1;
+    constexpr u32 m2 = KBITS >= 96 ? ~0u : KBITS <= 64 ? 0u : (1u << (KBITS - 64)) - 1, m3 = KBITS >= 128 ? ~0u : KBITS <= 96 ? 0u : (1u << (KBITS - 96)) - 1;
+    k0 &= m0; k1 &= m1; k2 &= m2; k3 &= m3;
+    u64 lo = ((u64)k1 << 32) | k0, hi = ((u64)k3 << 32) | k2;
+    if (SHIFT) {
+        const u64 rl = (info >> 26) & ((1u << SHIFT) - 1);
+        if (KBITS >= 64) hi |= rl << (KBITS - 64);
+        else {
+            lo |= rl << KBITS;
+            if (KBITS + SHIFT > 64) hi |= rl >> (64 - KBITS);
+        }
+    }
+    *lo_out = lo;
+    *hi_out = hi;
+}
+template <u32 NW, u32 KB, u32 SHIFT>
+__global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, const u64* __restrict__ rec, const u32* __restrict__ tags, const PartDesc* __restrict__ desc,
+                                                   u32 n_touched, IndexDev ix, unsigned long long* __restrict__ per_read_sum, u32* __restrict__ work_counter) {
+    constexpr u32 RS = RecGeom<NW>::RS;
+    BriskParams P = PP;
+    P.nw = NW;
+    P.stride = NW + 1;
+    __shared__ u64 s_ekey[2 * QF_ENT];
+    __shared__ u32 s_tab[QF_TABLE];
+    __shared__ u32 s_rw[WI_MAX_REC * RS + 4];
+    __shared__ u32 s_rsum[WI_MAX_REC];
+    __shared__ uint8_t s_ecnt[QF_ENT];
+    __shared__ uint8_t s_irec[QF_MAX_INST];
+    const u32 lane = threadIdx.x;
+    for (;;) {
+        u32 t0 = 0;
+        if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
+        t0 = (u32)__builtin_amdgcn_readfirstlane((int)t0);
+        if (t0 >= n_touched) break;
+        const BatchDescs bd = load_batch_descs(desc, min(t0 + lane, n_touched - 1));
+        const u32 t_n = min((u32)WI_BATCH, n_touched - t0);
+        for (u32 ti = 0; ti < t_n; ti++) {
+            const PartDesc d = batch_desc(bd, ti);
+            if (d.n_exist == 0) continue;  // nothing to find in an empty partition
+            const u32 r_end = d.r_begin + d.n_rec;
+            for (u32 ec = 0; ec < d.n_exist; ec += QF_ENT) {
+                const u32 ne = min(d.n_exist - ec, QF_ENT);
+                wave_sync();  // the previous chunk's probes are done
+#pragma unroll
+                for (u32 w = 0; w < QF_TABLE / 64; w++) s_tab[w * 64 + lane] = EMPTY_SLOT;
+                wave_sync();
+                for (u32 e = lane; e < ne; e += 64) {
+                    const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(ix.keys + 2 * (d.off + ec + e));
+                    s_ekey[2 * e] = kv.x;
+                    s_ekey[2 * e + 1] = kv.y;
+                    s_ecnt[e] = ix.counts[d.off + ec + e];
+                    u32 h = hash_key32(mk128(kv.x, kv.y)) & (QF_TABLE - 1);
+                    while (atomicCAS(&s_tab[h], EMPTY_SLOT, e) != EMPTY_SLOT) h = (h + 1) & (QF_TABLE - 1);
+                }
+                for (u32 rc = d.r_begin; rc < r_end;) {
+                    const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
+                    const RecRegs rr = load_rec_regs(P, rec, rc, avail, lane);
+                    const u64 my_hdr = NW == 1 ? rr.w1 : NW == 2 ? rr.w2 : NW == 3 ? rr.w3 : rr.w4;
+                    const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
+                    const u32 x0 = wave_incl_scan(raw_n, lane);
+                    const u32 nrec = (u32)__popcll(__ballot(lane < avail && x0 <= QF_MAX_INST));  // >= 1; a prefix
+                    const u32 ninst = (u32)__builtin_amdgcn_readlane((int)x0, (int)nrec - 1);
+                    wave_sync();  // the previous record chunk's sums have been read
+                    s_rsum[lane] = 0;
+                    if (lane < nrec) {
+                        const u32 start = x0 - raw_n;
+                        const u32 info = start | (raw_n << 10) | (hdr_idx0(my_hdr) << 18) | ((hdr_bucket(my_hdr) & ((1u << SHIFT) - 1)) << 26);
+                        store_rec_words<NW>(s_rw + lane * RS, rr, info);
+                        for (u32 j = 0; j < raw_n; j++) s_irec[start + j] = (uint8_t)lane;
+                    }
+                    wave_sync();
+                    for (u32 i0 = 0; i0 < ninst; i0 += 128) {  // two instances per lane in flight
+                        const u32 ia = i0 + lane, ib = i0 + 64 + lane;
+                        const bool va = ia < ninst, vb = ib < ninst;
+                        const u32 ra = s_irec[va ? ia : 0], rb = s_irec[vb ? ib : 0];
+                        u64 alo, ahi, blo, bhi;
+                        inst_key_words<NW, KB, SHIFT>(s_rw, ra, va ? ia : (s_rw[ra * RS + RecGeom<NW>::INFO] & 0x3ffu), &alo, &ahi);
+                        inst_key_words<NW, KB, SHIFT>(s_rw, rb, vb ? ib : (s_rw[rb * RS + RecGeom<NW>::INFO] & 0x3ffu), &blo, &bhi);
+                        u32 ha = hash_key32(mk128(alo, ahi)) & (QF_TABLE - 1), hb = hash_key32(mk128(blo, bhi)) & (QF_TABLE - 1);
+                        bool pa = va, pb = vb;
+                        u32 fa = 0, fb = 0;
+                        while (__any(pa || pb)) {
+                            const u32 ea = pa ? s_tab[ha] : EMPTY_SLOT, eb = pb ? s_tab[hb] : EMPTY_SLOT;
+                            const u32 xa = ea == EMPTY_SLOT ? 0 : ea, xb = eb == EMPTY_SLOT ? 0 : eb;
+                            const u64 qa0 = s_ekey[2 * xa], qa1 = s_ekey[2 * xa + 1], qb0 = s_ekey[2 * xb], qb1 = s_ekey[2 * xb + 1];
+                            if (pa) {
+                                if (ea == EMPTY_SLOT) pa = false;
+                                else if (qa0 == alo && qa1 == ahi) {
+                                    fa = s_ecnt[ea];
+                                    pa = false;
+                                } else ha = (ha + 1) & (QF_TABLE - 1);
+                            }
+                            if (pb) {
+                                if (eb == EMPTY_SLOT) pb = false;
+                                else if (qb0 == blo && qb1 == bhi) {
+                                    fb = s_ecnt[eb];
+                                    pb = false;
+                                } else hb = (hb + 1) & (QF_TABLE - 1);
+                            }
+                        }
+                        if (fa) atomicAdd(&s_rsum[ra], fa);
+                        if (fb) atomicAdd(&s_rsum[rb], fb);
+                    }
+                    wave_sync();
+                    if (lane < nrec) {
+                        const u32 sum = s_rsum[lane];
+                        if (sum) atomicAdd(&per_read_sum[tags[rc + lane]], (unsigned long long)sum);
+                    }
+                    rc += nrec;
+                }
+            }
+        }
+    }
+}
+
 // ===========================================================================
 // k_enumerate: entries of partitions [p_begin, p_end) in order; out_base[p - p_begin]
 // is the exclusive prefix of dir_cnt over that range (Brisk::next yields unhashed k-mers).

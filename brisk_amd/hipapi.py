@@ -110,7 +110,7 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_reallocate", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_export_hist_add", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
+    "brisk_hip_get_packed", "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_export_hist_add", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
@@ -137,6 +137,7 @@ def load() -> C.CDLL:
     L.brisk_hip_get_layout.argtypes = [vp, C.POINTER(_Layout)]
     L.brisk_hip_insert_reads.argtypes = [vp, _u8p, _u64p, u64]
     L.brisk_hip_insert_packed.argtypes = [vp, vp, vp, u64]
+    L.brisk_hip_get_packed.argtypes = [vp, vp, vp, u64, vp]
     L.brisk_hip_get_reads.argtypes = [vp, _u8p, _u64p, u64, _u64p]
     L.brisk_hip_lookup.argtypes = [vp, _u64p, _u64p, _u8p, u64, _u8p, _u8p]
     L.brisk_hip_enumerate.argtypes = [vp, C.POINTER(u64), _u64p, _u64p, _u8p, _u8p, u64, C.POINTER(u64)]
@@ -321,6 +322,10 @@ class BriskHip:
     # ---- device-buffer paths (pointers are ints: tensor.data_ptr())
     def insert_packed(self, d_packed: int, d_starts: int, n_reads: int):
         self._chk(self.L.brisk_hip_insert_packed(self.h, d_packed, d_starts, n_reads))
+
+    def get_packed(self, d_packed: int, d_starts: int, n_reads: int, d_sums: int):
+        """per-read sums of counts (query_sequence), reads and sums on the device"""
+        self._chk(self.L.brisk_hip_get_packed(self.h, d_packed, d_starts, n_reads, d_sums))
 
     def scan_bound(self, d_starts: int, n_reads: int) -> int:
         out = C.c_uint64()

@@ -157,6 +157,9 @@ int brisk_hip_insert_packed(brisk_hip_index *h, const uint32_t *d_packed, const 
  * super-k-mer after the first whose minimizer value is 0 (counter.cpp:304-306). */
 int brisk_hip_get_reads(brisk_hip_index *h, const char *bases, const uint64_t *offsets, uint64_t n_reads,
                         uint64_t *per_read_sum);
+/* the same with reads and sums resident on the device (layout of brisk_hip_insert_packed; d_per_read_sum[n_reads]) */
+int brisk_hip_get_packed(brisk_hip_index *h, const uint32_t *d_packed, const uint64_t *d_starts, uint64_t n_reads,
+                         uint64_t *d_per_read_sum);
 
 /* point lookups of UNHASHED (kmer_s, minimizer_idx) pairs, as Brisk::get takes them.
  * HOST arrays; out_found[i] in {0,1}; out_data[i] valid when found. */
