@@ -436,6 +436,7 @@ struct BinLayout {
     u32 bin_cap;
     u64* ovf;
     u64 n_ovf;
+    const u32* tags;  // query mode: the read of every record, laid out like the records: [n_parts * bin_cap] binned, then the overflow records'
 };
 int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist, const BinLayout* bl = nullptr);
 
@@ -813,17 +814,22 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
     return fail(h, BRISK_HIP_EHIP, "scan overflowed its exact bound");
 }
 
-// The binned insert of one batch (DESIGN.md section 4): the scan writes every record straight into its partition's bin --
-// the rank the histogram atomic returns is the slot -- so no staging copy and no k_scatter pass exist; the few records
-// beyond a bin (bin_cap is about twice the expected mean) are moved by the classic scatter.  *applied = false when the
-// batch does not qualify (nothing has been touched then) and the classic path must take it.
-int insert_packed_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool* applied) {
+// the parameter sets k_insert_fast / k_query_fast are instantiated for (the only kernels that read the binned layout in query mode)
+static bool has_fast_geometry(const BriskParams& P) {
+    return (P.nw == 3 && P.kb == 49 && P.shift >= 1 && P.shift <= 4) || (P.nw == 2 && P.kb == 17 && P.shift == 4) || (P.nw == 2 && P.kb == 20 && P.shift == 0);
+}
+
+// Scan a batch straight into per-partition bins (insert or query mode).  *applied = false: the batch does not qualify, or its
+// records did not fit (nothing of the index has been touched): the classic path takes it.
+int scan_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool query_mode, bool* applied, BinLayout* bl, u64* n_rec_out) {
     *applied = false;
     static const long forced = getenv("BRISK_BINS") ? atol(getenv("BRISK_BINS")) : -1;  // 0: never; S > 0: always, with bins of S records (tests)
     if (forced == 0 || h->entry_ids || h->scan_v1 || h->P.n_owners > 1) return BRISK_HIP_OK;
     // minimizers short enough for class bits are few and unevenly used: a tenth of the partitions hold everything, and bins sized for
     // the mean overflow
     if (forced < 0 && h->P.cls_bits) return BRISK_HIP_OK;
+    static const bool query_generic = getenv("BRISK_QUERY_GENERIC") != nullptr;
+    if (query_mode && (query_generic || !has_fast_geometry(h->P))) return BRISK_HIP_OK;
     int rc;
     u64 bound = 0, in_long = 0;
     if ((rc = count_kmers(h, d_starts, n_reads, &bound, &in_long))) return rc;
@@ -838,19 +844,38 @@ int insert_packed_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_s
     const u64 ovf_cap = est / 8 + 65536;
     if ((rc = ensure(h, h->bins, bytes))) return rc == BRISK_HIP_ENOMEM ? (h->err.clear(), BRISK_HIP_OK) : rc;
     if ((rc = ensure(h, h->staging, ovf_cap * h->P.stride * 8))) return rc;
+    u32* tags = nullptr;
+    if (query_mode) {
+        if ((rc = ensure(h, h->tags_a, (h->n_parts * cap + ovf_cap) * 4))) return rc == BRISK_HIP_ENOMEM ? (h->err.clear(), BRISK_HIP_OK) : rc;
+        tags = (u32*)h->tags_a.p;
+    }
     h->scan_hist_valid = false;
     HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
-    ScanOut out{nullptr, 0, h->d_small, h->d_hist, (u32*)(h->d_small + 1), nullptr, nullptr, (u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, ovf_cap, h->d_small + 7};
+    ScanOut out{nullptr, 0, h->d_small, h->d_hist, (u32*)(h->d_small + 1), tags, nullptr, (u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, ovf_cap, h->d_small + 7};
     ChunkCtl cc{nullptr, nullptr, nullptr, 0u};
-    if ((rc = launch_scan(h, d_packed, d_starts, n_reads, out, false, false, cc))) return rc;
+    if ((rc = launch_scan(h, d_packed, d_starts, n_reads, out, query_mode, false, cc))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if ((u32)h->h_small[1]) return BRISK_HIP_OK;  // more records beyond the bins than the overflow buffer holds: the classic path takes the batch
-    const u64 n_rec = h->h_small[0];
-    BinLayout bl{(u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, h->h_small[7]};
+    *n_rec_out = h->h_small[0];
+    *bl = BinLayout{(u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, h->h_small[7], tags};
+    *applied = true;
+    return BRISK_HIP_OK;
+}
+
+// The binned insert of one batch (DESIGN.md section 4): the scan writes every record straight into its partition's bin --
+// the rank the histogram atomic returns is the slot -- so no staging copy and no k_scatter pass exist; the few records
+// beyond a bin (bin_cap is about twice the expected mean) are moved by the classic scatter.  *applied = false when the
+// batch does not qualify (nothing has been touched then) and the classic path must take it.
+int insert_packed_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool* applied) {
+    BinLayout bl{};
+    u64 n_rec = 0;
+    int rc = scan_binned(h, d_packed, d_starts, n_reads, false, applied, &bl, &n_rec);
+    if (rc || !*applied) return rc;
+    *applied = false;
     rc = insert_records_once(h, nullptr, n_rec, true, &bl);
     if (rc == BRISK_HIP_ENOMEM) {  // the single-pass arena reserve does not fit: the classic path can split the batch (nothing was written)
         h->err.clear();
@@ -877,12 +902,18 @@ int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_sta
 
 // records (with a tag each) -> d_sums[tag] += sum of the counts of the record's k-mers that are present.
 // d_hist holds the records' per-partition histogram; d_sums must be zeroed by the caller.
-int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums);
+int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums, const BinLayout* bl = nullptr);
 
 int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, unsigned long long* d_sums) {
     // d_sums[n_reads] must be zeroed by the caller
     u64 n_rec = 0;
     int rc;
+    {  // one pass over the records, as in the insert: the scan bins them (and their reads' indices) by partition
+        BinLayout bl{};
+        bool binned = false;
+        if ((rc = scan_binned(h, d_packed, d_starts, n_reads, true, &binned, &bl, &n_rec))) return rc;
+        if (binned) return n_rec ? query_records_impl(h, nullptr, nullptr, n_rec, d_sums, &bl) : BRISK_HIP_OK;
+    }
     bool hist_ok = true;
     if ((rc = scan_to_staging(h, d_packed, d_starts, n_reads, true, true, &n_rec, &hist_ok))) return rc;
     if (n_rec == 0) return BRISK_HIP_OK;
@@ -894,30 +925,40 @@ int query_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_star
     return query_records_impl(h, (const u64*)h->staging.p, (const u32*)h->tags_a.p, n_rec, d_sums);
 }
 
-int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums) {
+// `bl`: the records (and bl->tags) lie in per-partition bins, the ones beyond them in bl->ovf (fast geometries only); else d_rec / d_tags
+int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, u64 n_rec, unsigned long long* d_sums, const BinLayout* bl) {
     const BriskParams& P = h->P;
     h->scan_hist_valid = false;
     int rc;
-    if ((rc = prefix_partitions(h))) return rc;
+    const u64 n_move = bl ? bl->n_ovf : n_rec;
+    if (n_move && (rc = prefix_partitions(h, bl ? bl->bin_cap : 0u))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 2, 0, 8, h->stream));
     if ((rc = list_touched(h, (u32*)(h->d_small + 2)))) return rc;
-    if ((rc = ensure(h, h->parted, n_rec * P.stride * 8))) return rc;
-    if ((rc = ensure(h, h->tags_b, n_rec * 4))) return rc;
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_rec, 256)), dim3(256), 0, h->stream, P, d_rec, n_rec, h->d_cur32,
-                       (u64*)h->parted.p, 0, d_tags, (u32*)h->tags_b.p, h->ix.err);
+    if (n_move) {
+        ProfScope ps(h, S_SCATTER);
+        if ((rc = ensure(h, h->parted, n_move * P.stride * 8))) return rc;
+        if ((rc = ensure(h, h->tags_b, n_move * 4))) return rc;
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_move, 256)), dim3(256), 0, h->stream, P, bl ? (const u64*)bl->ovf : d_rec, n_move, h->d_cur32, (u64*)h->parted.p, 0,
+                           bl ? bl->tags + h->n_parts * bl->bin_cap : d_tags, (u32*)h->tags_b.p, h->ix.err);
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const u32 n_touched = (u32)h->h_small[2];
     if (n_touched == 0) return BRISK_HIP_OK;
     if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
-    hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, h->d_off, h->d_touched, n_touched, h->ix.dir,
-                       (PartDesc*)h->desc.p, h->d_small + 3, 0u);
-    if (int lrc = launch_check(h, "k_need")) return lrc;
+    {
+        ProfScope ps(h, S_TOUCHED);
+        hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, (bl && !n_move) ? (const u32*)nullptr : h->d_off,
+                           h->d_touched, n_touched, h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3, bl ? bl->bin_cap : 0u);
+        if (int lrc = launch_check(h, "k_need")) return lrc;
+    }
     {
         ProfScope ps(h, S_QUERY);
         HIPCHK(h, hipMemsetAsync(h->d_small + 6, 0, 8, h->stream));
         const u32 batches = (n_touched + WI_BATCH - 1) / WI_BATCH;
+        const RecSrc src{bl ? bl->bins : (u64*)h->parted.p, (const u64*)h->parted.p, bl ? bl->bin_cap : 0u};
+        const u32* tags_binned = bl ? bl->tags : nullptr;
         auto resident = [&](const void* fn) -> u32 {  // persistent waves: as many as the device keeps resident
             int per_cu = 0, cus = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
@@ -926,14 +967,16 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
         };
 #define LAUNCH_QUERY_FAST(NW, KB, SH)                                                                                                               \
     hipLaunchKernelGGL((k_query_fast<NW, KB, SH>), dim3(std::min<u32>(batches, resident((const void*)k_query_fast<NW, KB, SH>))), dim3(64), 0, h->stream, P, \
-                       (const u64*)h->parted.p, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6))
+                       src, tags_binned, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6))
         static const bool generic_only = getenv("BRISK_QUERY_GENERIC") != nullptr;  // A/B and tests: force the run-time body
-        if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_QUERY_FAST(3, 49, 4);       // k63 m21 b14
-        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 3) LAUNCH_QUERY_FAST(3, 49, 3);  // (sharded, 2^25..2^27 partitions)
-        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_QUERY_FAST(3, 49, 2);
-        else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_QUERY_FAST(3, 49, 1);
-        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_QUERY_FAST(2, 17, 4);  // k31 m15 b14 (apps/counter.cpp:355)
-        else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_QUERY_FAST(2, 20, 0);  // k31 m11 b11
+        const bool fast = bl || !generic_only;
+        if (fast && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_QUERY_FAST(3, 49, 4);       // k63 m21 b14
+        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 3) LAUNCH_QUERY_FAST(3, 49, 3);  // (sharded, 2^25..2^27 partitions)
+        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_QUERY_FAST(3, 49, 2);
+        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_QUERY_FAST(3, 49, 1);
+        else if (fast && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_QUERY_FAST(2, 17, 4);  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (fast && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_QUERY_FAST(2, 20, 0);  // k31 m11 b11
+        else if (bl) return fail(h, BRISK_HIP_EHIP, "binned query without a kernel for this geometry");
         else
             hipLaunchKernelGGL(k_query, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (const u64*)h->parted.p, (const u32*)h->tags_b.p,
                                (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6));

@@ -132,8 +132,11 @@ __device__ __forceinline__ void inst_key_words(const u32* s_rw, u32 r, u32 i, u6
     *hi_out = hi;
 }
 template <u32 NW, u32 KB, u32 SHIFT>
-__global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, const u64* __restrict__ rec, const u32* __restrict__ tags, const PartDesc* __restrict__ desc,
-                                                   u32 n_touched, IndexDev ix, unsigned long long* __restrict__ per_read_sum, u32* __restrict__ work_counter) {
+__global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, const u32* __restrict__ tags_binned, const u32* __restrict__ tags,
+                                                   const PartDesc* __restrict__ desc, u32 n_touched, IndexDev ix, unsigned long long* __restrict__ per_read_sum,
+                                                   u32* __restrict__ work_counter) {
+    // records and their reads' indices: classic layout (src.bin_cap == 0) src.rec / tags in partition order; binned: record i of a
+    // partition in its bin (tags_binned alongside) for i < bin_cap, beyond it among the overflow records src.ovf / tags (RecSrc)
     constexpr u32 RS = RecGeom<NW>::RS;
     BriskParams P = PP;
     P.nw = NW;
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, const u64* __
                 }
                 for (u32 rc = d.r_begin; rc < r_end;) {
                     const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
-                    const RecRegs rr = load_rec_regs(P, rec, rc, avail, lane);
+                    const RecRegs rr = load_part_recs(P, src, d.part, d.r_begin, rc, avail, lane);
                     const u64 my_hdr = NW == 1 ? rr.w1 : NW == 2 ? rr.w2 : NW == 3 ? rr.w3 : rr.w4;
                     const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
                     const u32 x0 = wave_incl_scan(raw_n, lane);
@@ -222,7 +225,15 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, const u64* __
                     wave_sync();
                     if (lane < nrec) {
                         const u32 sum = s_rsum[lane];
-                        if (sum) atomicAdd(&per_read_sum[tags[rc + lane]], (unsigned long long)sum);
+                        if (sum) {
+                            u32 tag;
+                            if (!src.bin_cap) tag = tags[rc + lane];
+                            else {
+                                const u32 i = rc - d.r_begin + lane;
+                                tag = i < src.bin_cap ? tags_binned[(u64)d.part * src.bin_cap + i] : tags[d.r_begin + i - src.bin_cap];
+                            }
+                            atomicAdd(&per_read_sum[tag], (unsigned long long)sum);
+                        }
                     }
                     rc += nrec;
                 }

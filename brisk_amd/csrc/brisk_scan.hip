@@ -227,6 +227,7 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
             const u32 rank = (u32)atomicAdd(&out.hist[part], 1ull | ((unsigned long long)np << 32));
             if (rank < out.bin_cap) {
                 r = out.bins + ((u64)part * out.bin_cap + rank) * P.stride;
+                if (out.tag) out.tag[(u64)part * out.bin_cap + rank] = tag;  // query mode: the records' reads, laid out like the records
             } else {
                 const unsigned long long o = atomicAdd(out.n_ovf, 1ull);
                 if (o >= out.ovf_cap) {
@@ -234,6 +235,7 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
                     return;
                 }
                 r = out.ovf + o * P.stride;
+                if (out.tag) out.tag[((u64)out.bin_cap << P.part_bits) + o] = tag;
             }
         } else {
             r = out.rec + slot * P.stride;
