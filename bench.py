@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--part-bits", type=int, default=0, help="log2(#partitions); 0: library default")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000, help="reads of the CPU baseline sample (about 15 s of the reference on the box's host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--get", action="store_true", help="also time the get path afterwards (N=1): per-read sums of counts over the same reads; reported under \"get\"")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     args = ap.parse_args()
@@ -165,6 +166,25 @@ def main():
               "every_kmer_counted_once": chk[1] == total_reads * max(L - k + 1, 0),
               "digest_mod_2_64": (chk[2] + (chk[3] << 22) + (chk[4] << 44)) % (1 << 64)}
 
+    get_leg = None
+    if args.get and N == 1:
+        # query_sequence over the same reads against the index the last step built (apps/counter.cpp:281-310); not part of `value`
+        sums = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        ix.get_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, sums.data_ptr())  # warm-up (buffers)
+        ix.profile_reset()
+        ix.profile_enable(True)
+        torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            ix.get_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, sums.data_ptr())
+        torch.cuda.synchronize(dev)
+        tg = (time.perf_counter() - tg) / args.steps
+        total = int(sums.sum().item())
+        get_leg = {"ms_per_step": round(tg * 1e3, 3), "kmers_queried_per_s": round(n_reads * max(L - k + 1, 0) / tg, 1),
+                   "sum_of_counts": total,
+                   "kernels_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ix.profile_read().items() if v["launches"]}}
+
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         value = entries_all / dt
@@ -198,6 +218,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line["verify"] = verify
+        if get_leg:
+            line["get"] = get_leg
         print(json.dumps(line))
     if N > 1:
         dist.destroy_process_group()
