@@ -38,9 +38,10 @@
  *                               brisk/Kmers.cpp:522-603, brisk/Brisk.hpp:123-161);
  *                               also the declared-but-undefined
  *                               Brisk::insert_sequence (brisk/Brisk.hpp:27)
- *   brisk_hip_get_reads         query_sequence (apps/counter.cpp:281-310) over
+ *   brisk_hip_get_reads / brisk_hip_get_packed
+ *                               query_sequence (apps/counter.cpp:281-310) over
  *                               Brisk::get_superkmer (brisk/Brisk.hpp:102-118) /
- *                               Brisk::get_sequence (brisk/Brisk.hpp:28)
+ *                               Brisk::get_sequence (brisk/Brisk.hpp:28); _packed: reads and sums on the device
  *   brisk_hip_lookup            Brisk::get (brisk/Brisk.hpp:64-69)
  *   brisk_hip_enumerate         Brisk::next / restart_kmer_enumeration
  *                               (brisk/Brisk.hpp:166-179, brisk/DenseMenuYo.hpp:476-521)
@@ -55,6 +56,9 @@
  *                               apps/counter.cpp:242-261) so that records can be
  *                               exchanged between GPUs (no reference counterpart:
  *                               the reference is single-process)
+ *   brisk_hip_export_hist / brisk_hip_export_hist_add / brisk_hip_insert_records_hist
+ *                               no reference counterpart: the per-partition record counts of a scan travel with
+ *                               the records so that the owner need not count them again
  *   brisk_hip_scan_query / brisk_hip_route_tagged / brisk_hip_query_records
  *                               the query path (apps/counter.cpp:281-310, brisk/Brisk.hpp:102-118) cut at the
  *                               same boundary, for a get across bucket-range shards
