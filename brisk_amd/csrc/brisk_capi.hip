@@ -942,8 +942,10 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
                            bl ? bl->tags + h->n_parts * bl->bin_cap : d_tags, (u32*)h->tags_b.p, h->ix.err);
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));  // arena slots handed out so far
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const u32 n_touched = (u32)h->h_small[2];
+    h->arena_used_host = h->h_small[5];
     if (n_touched == 0) return BRISK_HIP_OK;
     if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
@@ -965,22 +967,32 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
             return std::min<u32>((u32)per_cu * (u32)cus, INSERT_SLOTS);
         };
-#define LAUNCH_QUERY_FAST(NW, KB, SH)                                                                                                               \
-    hipLaunchKernelGGL((k_query_fast<NW, KB, SH>), dim3(std::min<u32>(batches, resident((const void*)k_query_fast<NW, KB, SH>))), dim3(64), 0, h->stream, P, \
+        // table chunks of 128 entries while the partitions average at most ~100 (a partition's arena slice is its entries + 25 %
+        // + 8: 135 slots per partition), which keeps twice the waves resident; else 256
+        static const long ent_env = getenv("BRISK_QUERY_ENT") ? atol(getenv("BRISK_QUERY_ENT")) : 0;  // experiments and tests: 128 | 256
+        const bool small = ent_env ? ent_env == 128 : h->arena_used_host / own_partitions(h).len <= 135;
+#define LAUNCH_QUERY_FAST_ENT(NW, KB, SH, ENT)                                                                                                                    \
+    hipLaunchKernelGGL((k_query_fast<NW, KB, SH, ENT>), dim3(std::min<u32>(batches, resident((const void*)k_query_fast<NW, KB, SH, ENT>))), dim3(64), 0, h->stream, P, \
                        src, tags_binned, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6))
+#define LAUNCH_QUERY_FAST(NW, KB, SH)                     \
+    {                                                     \
+        if (small) LAUNCH_QUERY_FAST_ENT(NW, KB, SH, 128); \
+        else LAUNCH_QUERY_FAST_ENT(NW, KB, SH, 256);       \
+    }
         static const bool generic_only = getenv("BRISK_QUERY_GENERIC") != nullptr;  // A/B and tests: force the run-time body
         const bool fast = bl || !generic_only;
-        if (fast && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_QUERY_FAST(3, 49, 4);       // k63 m21 b14
-        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 3) LAUNCH_QUERY_FAST(3, 49, 3);  // (sharded, 2^25..2^27 partitions)
-        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_QUERY_FAST(3, 49, 2);
-        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_QUERY_FAST(3, 49, 1);
-        else if (fast && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_QUERY_FAST(2, 17, 4);  // k31 m15 b14 (apps/counter.cpp:355)
-        else if (fast && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_QUERY_FAST(2, 20, 0);  // k31 m11 b11
+        if (fast && P.nw == 3 && P.kb == 49 && P.shift == 4) LAUNCH_QUERY_FAST(3, 49, 4)       // k63 m21 b14
+        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 3) LAUNCH_QUERY_FAST(3, 49, 3)  // (sharded, 2^25..2^27 partitions)
+        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_QUERY_FAST(3, 49, 2)
+        else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_QUERY_FAST(3, 49, 1)
+        else if (fast && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_QUERY_FAST(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (fast && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_QUERY_FAST(2, 20, 0)  // k31 m11 b11
         else if (bl) return fail(h, BRISK_HIP_EHIP, "binned query without a kernel for this geometry");
         else
             hipLaunchKernelGGL(k_query, dim3(std::min<u32>(batches, INSERT_SLOTS)), dim3(64), 0, h->stream, P, (const u64*)h->parted.p, (const u32*)h->tags_b.p,
                                (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6));
 #undef LAUNCH_QUERY_FAST
+#undef LAUNCH_QUERY_FAST_ENT
     }
     return launch_check(h, "k_query");
 }

@@ -99,9 +99,9 @@ __global__ void __launch_bounds__(64) k_query(BriskParams P, const u64* __restri
 // parks every instance in a slot of its own, 3.4 equal keys behind each other at 15x coverage, and walks all of them for
 // every entry).  Same results: per record the sum of the counts of its k-mers that are present, one atomic per record into
 // its read's sum.
-#define QF_ENT 256u           // entries per table chunk
-#define QF_TABLE 512u
-#define QF_MAX_INST 768u      // instances per chunk of <= 64 records (the info word's prefix field has 10 bits)
+// ENT: entries per table chunk.  The kernel needs 46 registers, so what decides how many waves are resident -- and with them,
+// as in k_insert, the time -- is its LDS: 256 entries, 64 records and 768 instances per chunk take 9.7 KB (4 waves per SIMD),
+// 128 / 32 / 384 take 4.9 KB (8 per SIMD).  The host picks 128 while the index averages at most 100 entries per partition.
 template <u32 NW, u32 KB, u32 SHIFT>
 __device__ __forceinline__ void inst_key_words(const u32* s_rw, u32 r, u32 i, u64* lo_out, u64* hi_out) {
     constexpr u32 RS = RecGeom<NW>::RS, INFO = RecGeom<NW>::INFO, KBITS = 2 * KB + 6;
@@ -131,22 +131,25 @@ __device__ __forceinline__ void inst_key_words(const u32* s_rw, u32 r, u32 i, u6
     *lo_out = lo;
     *hi_out = hi;
 }
-template <u32 NW, u32 KB, u32 SHIFT>
+template <u32 NW, u32 KB, u32 SHIFT, u32 ENT>
 __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, const u32* __restrict__ tags_binned, const u32* __restrict__ tags,
                                                    const PartDesc* __restrict__ desc, u32 n_touched, IndexDev ix, unsigned long long* __restrict__ per_read_sum,
                                                    u32* __restrict__ work_counter) {
     // records and their reads' indices: classic layout (src.bin_cap == 0) src.rec / tags in partition order; binned: record i of a
     // partition in its bin (tags_binned alongside) for i < bin_cap, beyond it among the overflow records src.ovf / tags (RecSrc)
     constexpr u32 RS = RecGeom<NW>::RS;
+    // (QF_MAX_INST: whole 32-bit words of instance marks per lane; the info word's prefix field has 10 bits.  The table is a
+    // quarter full at most with 128-entry chunks: a probe round costs the whole wave ~25 vector instructions whichever lane needs it)
+    constexpr u32 QF_ENT = ENT, QF_TABLE = 512, QF_REC = ENT / 4, QF_MAX_INST = ENT == 128 ? 256 : 768, IW = QF_MAX_INST / 256;
     BriskParams P = PP;
     P.nw = NW;
     P.stride = NW + 1;
     __shared__ u64 s_ekey[2 * QF_ENT];
     __shared__ u32 s_tab[QF_TABLE];
-    __shared__ u32 s_rw[WI_MAX_REC * RS + 4];
-    __shared__ u32 s_rsum[WI_MAX_REC];
-    __shared__ uint8_t s_ecnt[QF_ENT];
-    __shared__ uint8_t s_irec[QF_MAX_INST];
+    __shared__ u32 s_rw[QF_REC * RS + 4];
+    __shared__ u32 s_rsum[QF_REC];
+    __shared__ __attribute__((aligned(4))) uint8_t s_irec[QF_MAX_INST];
+    u32* irec32 = (u32*)s_irec;
     const u32 lane = threadIdx.x;
     for (;;) {
         u32 t0 = 0;
@@ -169,12 +172,12 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, c
                     const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(ix.keys + 2 * (d.off + ec + e));
                     s_ekey[2 * e] = kv.x;
                     s_ekey[2 * e + 1] = kv.y;
-                    s_ecnt[e] = ix.counts[d.off + ec + e];
+                    const u32 word = e | ((u32)ix.counts[d.off + ec + e] << 16);  // table word: entry of the chunk | its count
                     u32 h = hash_key32(mk128(kv.x, kv.y)) & (QF_TABLE - 1);
-                    while (atomicCAS(&s_tab[h], EMPTY_SLOT, e) != EMPTY_SLOT) h = (h + 1) & (QF_TABLE - 1);
+                    while (atomicCAS(&s_tab[h], EMPTY_SLOT, word) != EMPTY_SLOT) h = (h + 1) & (QF_TABLE - 1);
                 }
                 for (u32 rc = d.r_begin; rc < r_end;) {
-                    const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
+                    const u32 avail = min(r_end - rc, QF_REC);
                     const RecRegs rr = load_part_recs(P, src, d.part, d.r_begin, rc, avail, lane);
                     const u64 my_hdr = NW == 1 ? rr.w1 : NW == 2 ? rr.w2 : NW == 3 ? rr.w3 : rr.w4;
                     const u32 raw_n = lane < avail ? hdr_n(my_hdr) : 0;
@@ -182,45 +185,91 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, c
                     const u32 nrec = (u32)__popcll(__ballot(lane < avail && x0 <= QF_MAX_INST));  // >= 1; a prefix
                     const u32 ninst = (u32)__builtin_amdgcn_readlane((int)x0, (int)nrec - 1);
                     wave_sync();  // the previous record chunk's sums have been read
-                    s_rsum[lane] = 0;
+                    if (lane < QF_REC) s_rsum[lane] = 0;
+#pragma unroll
+                    for (u32 q = 0; q < IW; q++) irec32[q * 64 + lane] = 0;
+                    wave_sync();
                     if (lane < nrec) {
                         const u32 start = x0 - raw_n;
                         const u32 info = start | (raw_n << 10) | (hdr_idx0(my_hdr) << 18) | ((hdr_bucket(my_hdr) & ((1u << SHIFT) - 1)) << 26);
                         store_rec_words<NW>(s_rw + lane * RS, rr, info);
-                        for (u32 j = 0; j < raw_n; j++) s_irec[start + j] = (uint8_t)lane;
+                        if (raw_n) s_irec[start] = (uint8_t)(lane + 1);  // instance -> record: a mark on every record's first instance ...
                     }
                     wave_sync();
-                    for (u32 i0 = 0; i0 < ninst; i0 += 128) {  // two instances per lane in flight
-                        const u32 ia = i0 + lane, ib = i0 + 64 + lane;
-                        const bool va = ia < ninst, vb = ib < ninst;
-                        const u32 ra = s_irec[va ? ia : 0], rb = s_irec[vb ? ib : 0];
-                        u64 alo, ahi, blo, bhi;
-                        inst_key_words<NW, KB, SHIFT>(s_rw, ra, va ? ia : (s_rw[ra * RS + RecGeom<NW>::INFO] & 0x3ffu), &alo, &ahi);
-                        inst_key_words<NW, KB, SHIFT>(s_rw, rb, vb ? ib : (s_rw[rb * RS + RecGeom<NW>::INFO] & 0x3ffu), &blo, &bhi);
-                        u32 ha = hash_key32(mk128(alo, ahi)) & (QF_TABLE - 1), hb = hash_key32(mk128(blo, bhi)) & (QF_TABLE - 1);
-                        bool pa = va, pb = vb;
-                        u32 fa = 0, fb = 0;
-                        while (__any(pa || pb)) {
-                            const u32 ea = pa ? s_tab[ha] : EMPTY_SLOT, eb = pb ? s_tab[hb] : EMPTY_SLOT;
-                            const u32 xa = ea == EMPTY_SLOT ? 0 : ea, xb = eb == EMPTY_SLOT ? 0 : eb;
-                            const u64 qa0 = s_ekey[2 * xa], qa1 = s_ekey[2 * xa + 1], qb0 = s_ekey[2 * xb], qb1 = s_ekey[2 * xb + 1];
-                            if (pa) {
-                                if (ea == EMPTY_SLOT) pa = false;
-                                else if (qa0 == alo && qa1 == ahi) {
-                                    fa = s_ecnt[ea];
-                                    pa = false;
-                                } else ha = (ha + 1) & (QF_TABLE - 1);
-                            }
-                            if (pb) {
-                                if (eb == EMPTY_SLOT) pb = false;
-                                else if (qb0 == blo && qb1 == bhi) {
-                                    fb = s_ecnt[eb];
-                                    pb = false;
-                                } else hb = (hb + 1) & (QF_TABLE - 1);
-                            }
+                    {  // ... and a running maximum spreads the marks (records lie in lane order); a lane owns IW * 4 consecutive instances here
+                        u32 wv[IW], run = 0;
+#pragma unroll
+                        for (u32 q = 0; q < IW; q++) {
+                            wv[q] = irec32[lane * IW + q];
+                            run = op_max_u32(run, op_max_u32(op_max_u32(wv[q] & 0xff, (wv[q] >> 8) & 0xff), op_max_u32((wv[q] >> 16) & 0xff, wv[q] >> 24)));
                         }
-                        if (fa) atomicAdd(&s_rsum[ra], fa);
-                        if (fb) atomicAdd(&s_rsum[rb], fb);
+                        u32 carry = wave_prev_lane(wave_incl_max_scan(run));
+#pragma unroll
+                        for (u32 q = 0; q < IW; q++) {
+                            const u32 b0 = op_max_u32(carry, wv[q] & 0xff), b1 = op_max_u32(b0, (wv[q] >> 8) & 0xff);
+                            const u32 b2 = op_max_u32(b1, (wv[q] >> 16) & 0xff), b3 = op_max_u32(b2, wv[q] >> 24);
+                            carry = b3;
+                            irec32[lane * IW + q] = ((b0 - 1) & 0xff) | (((b1 - 1) & 0xff) << 8) | (((b2 - 1) & 0xff) << 16) | ((b3 - 1) << 24);
+                        }
+                    }
+                    wave_sync();
+                    for (u32 i0 = 0; i0 < ninst;) {
+                        if (ninst - i0 > 64) {  // two instances per lane in flight
+                            const u32 ia = i0 + lane, ib = i0 + 64 + lane;
+                            const bool vb = ib < ninst;
+                            const u32 ra = s_irec[ia], rb = s_irec[vb ? ib : ia];
+                            u64 alo, ahi, blo, bhi;
+                            inst_key_words<NW, KB, SHIFT>(s_rw, ra, ia, &alo, &ahi);
+                            inst_key_words<NW, KB, SHIFT>(s_rw, rb, vb ? ib : ia, &blo, &bhi);
+                            u32 ha = hash_key32(mk128(alo, ahi)) & (QF_TABLE - 1), hb = hash_key32(mk128(blo, bhi)) & (QF_TABLE - 1);
+                            bool pa = true, pb = vb;
+                            u32 fa = 0, fb = 0;
+                            while (__any(pa || pb)) {
+                                const u32 ea = pa ? s_tab[ha] : EMPTY_SLOT, eb = pb ? s_tab[hb] : EMPTY_SLOT;
+                                const u32 xa = ea == EMPTY_SLOT ? 0 : (ea & 0xffffu), xb = eb == EMPTY_SLOT ? 0 : (eb & 0xffffu);
+                                const u64 qa0 = s_ekey[2 * xa], qa1 = s_ekey[2 * xa + 1], qb0 = s_ekey[2 * xb], qb1 = s_ekey[2 * xb + 1];
+                                if (pa) {
+                                    if (ea == EMPTY_SLOT) pa = false;
+                                    else if (qa0 == alo && qa1 == ahi) {
+                                        fa = ea >> 16;
+                                        pa = false;
+                                    } else ha = (ha + 1) & (QF_TABLE - 1);
+                                }
+                                if (pb) {
+                                    if (eb == EMPTY_SLOT) pb = false;
+                                    else if (qb0 == blo && qb1 == bhi) {
+                                        fb = eb >> 16;
+                                        pb = false;
+                                    } else hb = (hb + 1) & (QF_TABLE - 1);
+                                }
+                            }
+                            if (fa) atomicAdd(&s_rsum[ra], fa);
+                            if (fb) atomicAdd(&s_rsum[rb], fb);
+                            i0 += 128;
+                        } else {  // the last <= 64
+                            const u32 ia = i0 + lane;
+                            const bool va = ia < ninst;
+                            const u32 ra = s_irec[va ? ia : i0];
+                            u64 alo, ahi;
+                            inst_key_words<NW, KB, SHIFT>(s_rw, ra, va ? ia : i0, &alo, &ahi);
+                            u32 ha = hash_key32(mk128(alo, ahi)) & (QF_TABLE - 1);
+                            bool pa = va;
+                            u32 fa = 0;
+                            while (__any(pa)) {
+                                const u32 ea = pa ? s_tab[ha] : EMPTY_SLOT;
+                                const u32 xa = ea == EMPTY_SLOT ? 0 : (ea & 0xffffu);
+                                const u64 qa0 = s_ekey[2 * xa], qa1 = s_ekey[2 * xa + 1];
+                                if (pa) {
+                                    if (ea == EMPTY_SLOT) pa = false;
+                                    else if (qa0 == alo && qa1 == ahi) {
+                                        fa = ea >> 16;
+                                        pa = false;
+                                    } else ha = (ha + 1) & (QF_TABLE - 1);
+                                }
+                            }
+                            if (fa) atomicAdd(&s_rsum[ra], fa);
+                            i0 += 64;
+                        }
                     }
                     wave_sync();
                     if (lane < nrec) {
