@@ -78,6 +78,12 @@ struct brisk_hip_index {
     // scratch
     DevBuf route_buf;
     DevBuf bins;  // binned layout: n_parts bins of bin_cap records
+    // Small insert batches are scanned at once and inserted later (flush_pending): their records collect here, their per-partition
+    // counts in d_hist, until there are enough of them for the insert to work at its density, or a call needs the index.
+    DevBuf pend;
+    u64 n_pend = 0;
+    bool pend_hist_ok = true;   // d_hist counts exactly the pending records
+    bool defer = true;          // brisk_hip_options.immediate_inserts == 0 and BRISK_DEFER != 0
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
@@ -608,11 +614,11 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
 // seams and, if a seam does not match, re-scanned whole; *hist_valid tells whether d_hist still
 // describes exactly the records in d_rec.
 int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, u64* d_rec, u64 cap, bool with_hist,
-              bool query_mode, u32* d_tags, u64* n_rec_out, u64* d_ret = nullptr, u64 kmer_bound = 0, bool* hist_valid = nullptr) {
+              bool query_mode, u32* d_tags, u64* n_rec_out, u64* d_ret = nullptr, u64 kmer_bound = 0, bool* hist_valid = nullptr, bool keep_hist = false) {
     if (hist_valid) *hist_valid = with_hist;
     if (with_hist) {
         h->scan_hist_valid = false;
-        HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
+        if (!keep_hist) HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));  // (keep_hist: add to the pending records' counts)
     }
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
     ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret, nullptr, 0u, nullptr, 0ull, nullptr};
@@ -885,14 +891,90 @@ int insert_packed_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_s
     return rc;
 }
 
+// ---- deferred inserts -------------------------------------------------------------------------------------------------------
+// The insert works on partitions: its time follows the number of partitions a batch touches, and only with 10-20 records in
+// each is that time spent on k-mers (50 M reads in one batch: 31 ms; in 25 batches of 2 M: 180 ms, on an index of 2^24
+// partitions).  The scan has no such threshold.  So a batch that would leave the partitions nearly empty is scanned right away
+// -- its records appended to h->pend, their per-partition counts added to d_hist -- and inserted together with the batches that
+// follow it, as soon as there are DEFER_FLUSH_AT records per partition or any call other than an insert needs the index or the
+// scratch the pending state lives in (enter()).  Results are those of inserting every batch at once: counts add up and wrap the
+// same way in any grouping (tests run the same inputs with BRISK_DEFER=0 and 1).
+#define DEFER_DIRECT_AT 10u   // batches estimated at this many records per partition or more are inserted directly
+#define DEFER_FLUSH_AT 12u    // pending records per partition at which they are inserted
+
+int flush_pending(brisk_hip_index* h) {
+    if (!h->n_pend) return BRISK_HIP_OK;
+    const u64 n = h->n_pend;
+    const bool hist_ok = h->pend_hist_ok;
+    h->n_pend = 0;  // whatever happens, the records are consumed (a failed insert is a failed insert)
+    h->pend_hist_ok = true;
+    return insert_records_impl(h, (const u64*)h->pend.p, n, hist_ok);
+}
+
+// room for `more` records behind the pending ones (contents kept)
+static int pend_reserve(brisk_hip_index* h, u64 more) {
+    const size_t rec_bytes = h->P.stride * 8, need = (h->n_pend + more) * rec_bytes;
+    if (h->pend.bytes >= need) return BRISK_HIP_OK;
+    DevBuf bigger;
+    int rc = ensure(h, bigger, std::max<size_t>(need, 2 * h->pend.bytes));
+    if (rc) return rc;
+    if (h->n_pend) HIPCHK(h, hipMemcpyAsync(bigger.p, h->pend.p, h->n_pend * rec_bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->pend.p) (void)hipFree(h->pend.p);
+    h->pend = bigger;
+    return BRISK_HIP_OK;
+}
+
+// scan a small batch into the pending records; *deferred = false: the batch is dense enough (or the index not of the kind) to be inserted directly
+int defer_batch(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads, bool* deferred) {
+    *deferred = false;
+    if (!h->defer || h->entry_ids || h->scan_v1 || h->P.n_owners > 1) return BRISK_HIP_OK;
+    int rc;
+    u64 bound = 0;
+    if ((rc = count_kmers(h, d_starts, n_reads, &bound))) return rc;
+    if (bound == 0) {
+        *deferred = true;  // nothing to insert
+        return BRISK_HIP_OK;
+    }
+    const u64 est = records_estimate(h, bound, n_reads);
+    if (est >= (u64)DEFER_DIRECT_AT * h->n_parts) return BRISK_HIP_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const u64 cap = attempt ? bound : est;
+        if ((rc = pend_reserve(h, cap))) return rc;
+        u64 n_rec = 0;
+        bool hist_ok = true;
+        const bool with_hist = h->pend_hist_ok;
+        rc = scan_impl(h, d_packed, d_starts, n_reads, (u64*)h->pend.p + h->n_pend * h->P.stride, cap, with_hist, false, nullptr, &n_rec, nullptr, bound, &hist_ok,
+                       /*keep_hist=*/h->n_pend > 0);
+        if (rc == BRISK_HIP_ECAPACITY) {  // the first guess was too small: what it counted before it stopped is in d_hist
+            h->pend_hist_ok = false;
+            h->err.clear();
+            continue;
+        }
+        if (rc) return rc;
+        if (!with_hist || !hist_ok) h->pend_hist_ok = false;
+        h->n_pend += n_rec;
+        *deferred = true;
+        if (h->n_pend >= (u64)DEFER_FLUSH_AT * h->n_parts) return flush_pending(h);
+        return BRISK_HIP_OK;
+    }
+    return fail(h, BRISK_HIP_EHIP, "scan overflowed its exact bound");
+}
+
+// what every entry point other than the inserts does first: the index as of all completed insert calls
+static int enter(brisk_hip_index* h) { return flush_pending(h); }
+
 int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 n_reads) {
     for (u64 r0 = 0; r0 < n_reads; r0 += h->max_batch_reads) {
         const u64 nb = std::min<u64>(h->max_batch_reads, n_reads - r0);
         u64 n_rec = 0;
         int rc;
-        bool binned = false;
-        if ((rc = insert_packed_binned(h, d_packed, d_starts + r0, nb, &binned))) return rc;
-        if (binned) continue;
+        bool done = false;
+        if ((rc = defer_batch(h, d_packed, d_starts + r0, nb, &done))) return rc;
+        if (done) continue;
+        if ((rc = flush_pending(h))) return rc;  // (the direct paths use d_hist)
+        if ((rc = insert_packed_binned(h, d_packed, d_starts + r0, nb, &done))) return rc;
+        if (done) continue;
         bool hist_ok = true;
         if ((rc = scan_to_staging(h, d_packed, d_starts + r0, nb, true, false, &n_rec, &hist_ok))) return rc;
         if ((rc = insert_records_impl(h, (const u64*)h->staging.p, n_rec, hist_ok))) return rc;
@@ -1132,7 +1214,7 @@ int drain_profile(brisk_hip_index* h) {
 void free_all(brisk_hip_index* h) {
     hipStreamSynchronize(h->stream);  // nothing of ours may be in flight when the arena is unmapped
     auto fr = [](void* p) { if (p) hipFree(p); };
-    for (DevBuf* b : {&h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+    for (DevBuf* b : {&h->pend, &h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);
@@ -1237,6 +1319,8 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     h->n_buckets = 1ull << (2 * b);
     h->max_batch_reads = o.max_batch_reads ? o.max_batch_reads : (1ull << 26);
     h->entry_ids = o.entry_ids != 0;
+    static const bool defer_env = !(getenv("BRISK_DEFER") && atoi(getenv("BRISK_DEFER")) == 0);  // BRISK_DEFER=0: every insert call completes before it returns
+    h->defer = defer_env && !o.immediate_inserts;
     h->device = o.device;
 
     auto init = [&]() -> int {
@@ -1401,6 +1485,8 @@ BRISK_API int brisk_hip_clear(brisk_hip_index* h) {
     h->arena_used_host = 0;
     h->nb_skmers = 0;
     h->dir_snapshot_valid = false;
+    h->n_pend = 0;  // records scanned and not yet inserted go with the index
+    h->pend_hist_ok = true;
     return BRISK_HIP_OK;
 }
 
@@ -1419,6 +1505,7 @@ BRISK_API int brisk_hip_sync(brisk_hip_index* h) {
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     return check_device_flags(h);
 }
 
@@ -1464,6 +1551,7 @@ BRISK_API int brisk_hip_get_reads(brisk_hip_index* h, const char* bases, const u
     if (h->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "get_reads on a sharded index sees one bucket range only: use scan_query / route_tagged / query_records");
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     return for_each_host_batch(h, bases, offsets, n_reads, [&](u64 r0, u64 nr) -> int {
         int rc;
         if ((rc = ensure(h, h->sums_tmp, nr * 8))) return rc;
@@ -1481,6 +1569,7 @@ BRISK_API int brisk_hip_get_packed(brisk_hip_index* h, const uint32_t* d_packed,
     if (!n_reads) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     HIPCHK(h, hipMemsetAsync(d_per_read_sum, 0, n_reads * 8, h->stream));
     for (u64 r0 = 0; r0 < n_reads; r0 += h->max_batch_reads) {  // the record tags of a batch are indices into its own slice of the sums
         const u64 nb = std::min<u64>(h->max_batch_reads, n_reads - r0);
@@ -1497,6 +1586,7 @@ BRISK_API int brisk_hip_lookup(brisk_hip_index* h, const uint64_t* kmer_lo, cons
     if (n == 0) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     int rc;
     if ((rc = ensure(h, h->lookup_buf, n * 19 + 64))) return rc;
     char* base = (char*)h->lookup_buf.p;
@@ -1525,6 +1615,7 @@ static int enumerate_impl(brisk_hip_index* h, uint64_t* cursor, uint64_t* out_lo
     if (out_ids && !h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "not an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     *n_out = 0;
     if (*cursor == 0 || !h->dir_snapshot_valid) {
         h->h_dir_cnt.resize(h->n_parts);
@@ -1590,6 +1681,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (!h) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     {
         int rcf = check_device_flags(h);
         if (rcf) return rcf;
@@ -1639,6 +1731,8 @@ BRISK_API int brisk_hip_reallocate(brisk_hip_index* from, brisk_hip_index* to) {
     if (from->entry_ids || to->entry_ids) return fail(h, BRISK_HIP_EINVAL, "reallocate: entry-id indexes are re-bucketed by the facade (DATA lives on the host)");
     if (to->P.n_owners > 1 || from->P.n_owners > 1) return fail(h, BRISK_HIP_EINVAL, "reallocate on a sharded index");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int frc = enter(from)) return fail(h, frc, "reallocate: " + from->err);
+    if (int frc = enter(to)) return frc;
     HIPCHK(h, hipStreamSynchronize(from->stream));
     const u32 k = from->P.k;
     // the old index's partition sizes
@@ -1694,6 +1788,7 @@ BRISK_API int brisk_hip_reallocate(brisk_hip_index* from, brisk_hip_index* to) {
 BRISK_API int brisk_hip_memory_info(brisk_hip_index* h, uint64_t out[4]) {
     if (!h || !out) return BRISK_HIP_EINVAL;
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     out[0] = h->use_vmm ? h->vm_keys.mapped + h->vm_counts.mapped + h->vm_ids.mapped : h->arena_cap * (h->entry_ids ? 21 : 17);
     out[1] = h->use_vmm ? h->vm_keys.reserved + h->vm_counts.reserved + h->vm_ids.reserved : 0;
     out[2] = pool_bytes();
@@ -1705,6 +1800,7 @@ BRISK_API int brisk_hip_checksum(brisk_hip_index* h, uint64_t out[3]) {
     if (!h || !out) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 24, h->stream));
     hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, h->stream, h->P, h->ix, (u32)h->n_parts, h->d_small);
     int rc;
@@ -1735,6 +1831,7 @@ BRISK_API int brisk_hip_scan_packed(brisk_hip_index* h, const uint32_t* d_packed
     if (!h || !n_records || (n_reads && (!d_packed || !d_starts)) || (cap_records && !d_records)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     *n_records = 0;
     if (!n_reads) {  // an empty piece of a sharded job still exports a (zero) histogram: the exchange is collective
         h->scan_hist_valid = false;
@@ -1768,6 +1865,7 @@ BRISK_API int brisk_hip_export_hist(brisk_hip_index* h, uint64_t* d_hist_out, ui
     if (!h || !d_hist_out || !partitions_per_owner) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
     HIPCHK(h, hipMemcpyAsync(d_hist_out, h->d_hist, h->n_parts * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1779,6 +1877,7 @@ BRISK_API int brisk_hip_export_hist_add(brisk_hip_index* h, uint64_t* d_hist_acc
     if (!h || !d_hist_acc || !partitions_per_owner) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist_add: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
     hipLaunchKernelGGL(k_add_u64, dim3(std::min<u32>(nblocks(h->n_parts, 1024), 8192)), dim3(256), 0, h->stream, (const unsigned long long*)h->d_hist, h->n_parts,
                        (unsigned long long*)d_hist_acc);
@@ -1792,6 +1891,7 @@ BRISK_API int brisk_hip_insert_records_hist(brisk_hip_index* h, const uint64_t* 
     if (!h || (n_records && (!d_records || !d_hist_slices || !n_slices))) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     h->scan_hist_valid = false;
     if (!n_records) return BRISK_HIP_OK;
@@ -1823,6 +1923,7 @@ static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint3
     if (!h || !counts || (n_records && (!d_records || !d_out))) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     const u32 no = h->P.n_owners;
     for (u32 i = 0; i < no; i++) counts[i] = 0;
     if (!n_records) return BRISK_HIP_OK;
@@ -1860,6 +1961,7 @@ BRISK_API int brisk_hip_insert_records(brisk_hip_index* h, const uint64_t* d_rec
     if (!h || (n_records && !d_records)) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     return insert_records_impl(h, d_records, n_records, false);
 }
@@ -1870,6 +1972,7 @@ BRISK_API int brisk_hip_scan_query(brisk_hip_index* h, const uint32_t* d_packed,
     if (n_reads >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 reads in one query batch");
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     *n_records = 0;
     if (!n_reads) return BRISK_HIP_OK;
     u64 n = 0, bound = 0;
@@ -1885,6 +1988,7 @@ BRISK_API int brisk_hip_query_records(brisk_hip_index* h, const uint64_t* d_reco
     if (n_records >= (1ull << 32)) return fail(h, BRISK_HIP_EINVAL, "more than 2^32-1 records in one batch");
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     if (!n_records) return BRISK_HIP_OK;
     int rc;
     if ((rc = ensure(h, h->tags_a, n_records * 4))) return rc;
@@ -1908,6 +2012,7 @@ BRISK_API int brisk_hip_scan_sequence(brisk_hip_index* h, const char* bases, uin
     if (!bases || !skm_ret || !skm_n || !km_lo || !km_hi || !km_idx || cap_kmers < nk) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     const uint64_t offs[2] = {0, len};
     // SuperKmerEnumerator::next yields whole vectors: no minimizer_idx classes in the routing ids of this scan (they are not used:
     // the records only carry the vectors to k_expand_records)
@@ -1988,6 +2093,7 @@ BRISK_API int brisk_hip_upsert_kmers(brisk_hip_index* h, const uint64_t* kmer_lo
         if (minimizer_idx[i] > h->P.w) return fail(h, BRISK_HIP_EINVAL, "minimizer_idx > k-m");
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     int rc;
     if (!h->arena_cap && (rc = ensure_arena(h, 1u << 16))) return rc;
     u64 *d_lo, *d_hi;
@@ -2024,6 +2130,7 @@ BRISK_API int brisk_hip_find_kmers(brisk_hip_index* h, const uint64_t* kmer_lo, 
     if (!n) return BRISK_HIP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
     int rc;
     u64 *d_lo, *d_hi;
     uint8_t *d_idx, *d_new;

@@ -94,7 +94,7 @@ def coef_table(m: int) -> np.ndarray:
 class _Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p), ("part_bits", C.c_uint32),
                 ("owner_rank", C.c_uint32), ("n_owners", C.c_uint32), ("arena_entries", C.c_uint64),
-                ("max_batch_reads", C.c_uint64), ("entry_ids", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("max_batch_reads", C.c_uint64), ("entry_ids", C.c_uint32), ("immediate_inserts", C.c_uint32)]
 
 
 class _Layout(C.Structure):
@@ -201,12 +201,12 @@ class BriskHip:
 
     def __init__(self, k: int, m: int, b: int, device: int = 0, stream: Optional[int] = None, part_bits: int = 0,
                  owner_rank: int = 0, n_owners: int = 1, arena_entries: int = 0, max_batch_reads: int = 0,
-                 entry_ids: bool = False):
+                 entry_ids: bool = False, immediate_inserts: bool = False):
         self.L = load()
         self.h = C.c_void_p()
         self.k, self.m, self.b = k, m, b
         opt = _Options(C.sizeof(_Options), device, stream, part_bits, owner_rank, n_owners, arena_entries, max_batch_reads,
-                       1 if entry_ids else 0, 0)
+                       1 if entry_ids else 0, 1 if immediate_inserts else 0)
         coef = coef_table(m) if 1 <= m <= 31 else np.zeros(4, np.float64)
         rc = self.L.brisk_hip_create(C.byref(self.h), k, m, b, 1, coef.ctypes.data_as(C.POINTER(C.c_double)), C.byref(opt))
         if rc:

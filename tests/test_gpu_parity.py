@@ -161,10 +161,55 @@ def test_kernel_variants_match_the_oracle(B):
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_variant_worker.py")
-    for extra in ({"BRISK_BINS": "2", "BRISK_QUERY_ENT": "256"}, {"BRISK_BINS": "64", "BRISK_QUERY_ENT": "128"}, {"BRISK_BINS": "0"}, {"BRISK_INSERT_GENERIC": "1", "BRISK_QUERY_GENERIC": "1", "BRISK_BINS": "0"}):
+    for extra in ({"BRISK_BINS": "2", "BRISK_QUERY_ENT": "256"}, {"BRISK_BINS": "64", "BRISK_QUERY_ENT": "128"}, {"BRISK_BINS": "0", "BRISK_DEFER": "0"},
+                  {"BRISK_INSERT_GENERIC": "1", "BRISK_QUERY_GENERIC": "1", "BRISK_BINS": "0"}):
         env = dict(os.environ, **extra)
         p = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and p.stdout.strip().endswith("ok 12"), (extra, p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_deferred_inserts_are_invisible(B, O):
+    """Small insert batches are scanned at once and inserted later (brisk_hip_options.immediate_inserts): the same index as with
+    immediate inserts whatever is called in between; with few partitions the pending records reach the flush threshold by
+    themselves (12 records per partition), with the default 2^24 they wait for the first call that needs the index."""
+    import torch
+    rng = random.Random(71)
+    reads = _random_reads(rng, 4000, 20000) + SPECIAL
+    flat, offs = oracle.pack_reads(reads)
+    d_bases = torch.from_numpy(flat).cuda()
+    d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+    for (k, m, b), pb in (((63, 21, 14), 10), ((63, 21, 14), 0), ((31, 11, 11), 0)):
+        want = O.count(reads, k, m, b)
+        q = reads[:50] + SPECIAL
+        qf, qo = oracle.pack_reads(q)
+        h = O.index_new(k, m, b)
+        got = {}
+        for immediate in (True, False):
+            with B.BriskHip(k, m, b, part_bits=pb, immediate_inserts=immediate) as ix:
+                torch.cuda.synchronize()
+                ix.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+                ix.sync()
+                seen = []
+                step = 150
+                for i, lo in enumerate(range(0, len(reads), step)):
+                    n = min(step, len(reads) - lo)
+                    ix.insert_packed(d_packed.data_ptr(), d_starts[lo:lo + n + 1].contiguous().data_ptr(), n)
+                    if i % 7 == 3:   # a reader in between sees everything inserted so far
+                        seen.append((i, ix.stats()["nb_skmers"], ix.get_reads(q).tolist()))
+                st = ix.stats()
+                got[immediate] = (sorted(oracle.multiset_lines(*ix.enumerate(), k)), st["nb_kmers"], st["nb_buckets"], seen)
+        assert got[True][:3] == want and got[False][:3] == want, (k, m, b, pb)
+        assert got[True][3] == got[False][3]
+        # and what the readers saw is what the oracle has after the same batches
+        for i, _, sums in got[False][3]:
+            hh = O.index_new(k, m, b)
+            upto = min((i + 1) * 150, len(reads))
+            f2, o2 = oracle.pack_reads(reads[:upto])
+            O.index_insert_reads(hh, f2, o2)
+            assert sums == O.index_query_reads(hh, qf, qo).tolist()
+            O.index_free(hh)
+        O.index_free(h)
 
 
 def test_scan_records_match_oracle_records(B, O):
