@@ -89,7 +89,9 @@ SPECIAL = ["A" * 150, "C" * 150, "G" * 150, "T" * 150, "AC" * 75, "ACG" * 50, "A
            "A" * 70 + "ACGTTGCA" * 10, "acgt" * 40, "ACGTTGCATGCA" * 13]
 
 
-@pytest.mark.parametrize("k,m,b", CONFIGS + [(33, 11, 7), (47, 15, 10), (21, 7, 3), (63, 31, 12), (41, 21, 5), (63, 21, 4), (32, 13, 6), (34, 21, 9), (31, 11, 11)])
+@pytest.mark.parametrize("k,m,b", CONFIGS + [(33, 11, 7), (47, 15, 10), (21, 7, 3), (63, 31, 12), (41, 21, 5), (63, 21, 4), (32, 13, 6), (34, 21, 9), (31, 11, 11),
+                                            # short minimizers: a minimizer_idx class bit in the routing id (k - m + 1 >= 8), or not (15, 11, 5)
+                                            (63, 11, 4), (63, 11, 11), (20, 9, 3), (18, 11, 9), (15, 11, 5), (40, 7, 7), (33, 9, 1)])
 def test_random_and_degenerate_reads_vs_oracle(B, O, k, m, b):
     rng = random.Random(k * 1000 + m * 10 + b)
     reads = _random_reads(rng, 500, 5000) + SPECIAL
@@ -99,6 +101,16 @@ def test_random_and_degenerate_reads_vs_oracle(B, O, k, m, b):
     got = gpu_count(B, reads, k, m, b)
     assert got[1:] == want[1:]
     assert got[0] == want[0]
+    if m <= 11:  # and the get, whose records the scan cuts the same way
+        q = reads[:120] + SPECIAL
+        qf, qo = oracle.pack_reads(q)
+        flat, offs = oracle.pack_reads(reads)
+        h = O.index_new(k, m, b)
+        O.index_insert_reads(h, flat, offs)
+        with B.BriskHip(k, m, b) as ix:
+            ix.insert_reads(reads)
+            assert np.array_equal(ix.get_reads(q), O.index_query_reads(h, qf, qo))
+        O.index_free(h)
 
 
 def test_insert_is_incremental_and_order_independent(B, O):

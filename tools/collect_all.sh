@@ -11,4 +11,6 @@ bash tools/collect_sq.sh ${TAG} --reads 50000000
 bash tools/collect_sq.sh ${TAG}_k31 --k 31 --m 11 --b 11 --reads 10000000
 python3 bench.py --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_50M.json 2> gpurun_out/bench_${TAG}_50M.err
 python3 bench.py --k 31 --m 11 --b 11 --reads 10000000 --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_k31_10M.json 2> gpurun_out/bench_${TAG}_k31_10M.err
+python3 bench.py --steps 5 --warmup 2 --get --no-cpu-baseline > gpurun_out/bench_${TAG}_50M_get.json 2> gpurun_out/bench_${TAG}_50M_get.err
+bash tools/sq_get.sh > gpurun_out/sq_get_${TAG}.log 2>&1 || true
 echo done

@@ -9,4 +9,6 @@ python3 tools/make_traffic_json.py gpurun_out/prof_${TAG}_k31 profiles/${TAG}_k3
 { echo "# the same for: --k 31 --m 11 --b 11 --reads 10000000"; cat gpurun_out/sq_${TAG}_k31/summary.txt; } > profiles/${TAG}_k31_sq_counters.txt
 cp gpurun_out/bench_${TAG}_50M.json profiles/${TAG}_bench_50M.json
 cp gpurun_out/bench_${TAG}_k31_10M.json profiles/${TAG}_bench_k31_10M.json
+cp gpurun_out/bench_${TAG}_50M_get.json profiles/${TAG}_bench_50M_get.json
+[ -f gpurun_out/sq_get/summary.txt ] && { echo "# SQ counters of the get path, 10 M reads (insert once, three get_packed calls): tools/sq_get.sh"; cat gpurun_out/sq_get/summary.txt; } > profiles/${TAG}_get_sq_counters.txt
 ls -la profiles/ | grep ${TAG}
