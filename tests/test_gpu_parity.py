@@ -224,6 +224,18 @@ def test_deferred_inserts_are_invisible(B, O):
         O.index_free(h)
 
 
+def test_randomised_parity_soak(B):
+    """25 s of tests/fuzz_parity.py: random (k, m, b), partition counts, read sets with repeats and homopolymers, ragged
+    lengths, random batch splits with readers in between, deferred and immediate inserts -- index and get against the oracle."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py")
+    p = subprocess.run([sys.executable, worker, "25", "7"], capture_output=True, text=True, timeout=600)
+    last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+    assert p.returncode == 0 and last.startswith("done") and int(last.split()[1]) >= 20, (p.stdout[-2000:], p.stderr[-3000:])
+
+
 def test_scan_records_match_oracle_records(B, O):
     """The scan kernel's output, record by record (the super-k-mer boundary of the path)."""
     import torch
