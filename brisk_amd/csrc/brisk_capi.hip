@@ -915,8 +915,11 @@ int flush_pending(brisk_hip_index* h) {
 static int pend_reserve(brisk_hip_index* h, u64 more) {
     const size_t rec_bytes = h->P.stride * 8, need = (h->n_pend + more) * rec_bytes;
     if (h->pend.bytes >= need) return BRISK_HIP_OK;
+    // a stream of real batches gets all it will ever need at once (the flush threshold plus the largest deferrable batch: 12 GB on
+    // 2^24 partitions at k = 63) -- growing there means copying gigabytes; tiny indexes grow by doubling
+    const size_t full = (size_t)(DEFER_FLUSH_AT + DEFER_DIRECT_AT) * h->n_parts * rec_bytes;
     DevBuf bigger;
-    int rc = ensure(h, bigger, std::max<size_t>(need, 2 * h->pend.bytes));
+    int rc = ensure(h, bigger, need > ((size_t)256 << 20) ? std::max(need, full) : std::max<size_t>(need, 2 * h->pend.bytes));
     if (rc) return rc;
     if (h->n_pend) HIPCHK(h, hipMemcpyAsync(bigger.p, h->pend.p, h->n_pend * rec_bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
