@@ -78,6 +78,7 @@ struct brisk_hip_index {
     // scratch
     DevBuf route_buf;
     DevBuf bins;  // binned layout: n_parts bins of bin_cap records
+    DevBuf huge;  // [0] number, [1..HUGE_LIST_CAP] descriptor indices of the batch's huge partitions (k_insert_huge)
     // Small insert batches are scanned at once and inserted later (flush_pending): their records collect here, their per-partition
     // counts in d_hist, until there are enough of them for the insert to work at its density, or a call needs the index.
     DevBuf pend;
@@ -445,6 +446,7 @@ struct BinLayout {
     const u32* tags;  // query mode: the read of every record, laid out like the records: [n_parts * bin_cap] binned, then the overflow records'
 };
 int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist, const BinLayout* bl = nullptr);
+#define HUGE_LIST_CAP 65536u   // huge partitions of one batch (k_insert_huge)
 
 // Records in any split are still a valid batch: when the single-pass arena reserve for a batch does not
 // fit the device (BRISK_HIP_ENOMEM is raised before anything is written), insert it as two halves.
@@ -496,17 +498,31 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const u32 n_touched = (u32)h->h_small[2];
     if (n_touched == 0) return BRISK_HIP_OK;
+    // partitions of more k-mer instances than this go to k_insert_huge, a workgroup each (0: none; entry-id indexes keep ids per entry,
+    // which that kernel does not)
+    static const long huge_env = getenv("BRISK_HUGE_AT") ? atol(getenv("BRISK_HUGE_AT")) : -1;  // tests: a small threshold sends ordinary partitions there
+    const u32 huge_at = h->entry_ids ? 0u : huge_env >= 0 ? (u32)huge_env : 16384u;
     {
         ProfScope ps(h, S_TOUCHED);
         if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
+        if (huge_at) {
+            if ((rc = ensure(h, h->huge, (size_t)(HUGE_LIST_CAP + 1) * 4))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->huge.p, 0, 4, h->stream));
+        }
         hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, (bl && !n_move) ? (const u32*)nullptr : h->d_off,
-                           h->d_touched, n_touched, h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3, bl ? bl->bin_cap : 0u);
+                           h->d_touched, n_touched, h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3, bl ? bl->bin_cap : 0u, huge_at, huge_at ? (u32*)h->huge.p : (u32*)nullptr,
+                           (u32)HUGE_LIST_CAP);
         if (int lrc = launch_check(h, "k_need")) return lrc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 3, h->d_small + 3, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));
+    h->h_small[4] = 0;
+    if (huge_at) HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->huge.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->arena_used_host = h->h_small[5];
+    // (more huge partitions than the list holds: none is diverted, the wave kernels take them all)
+    const u32 n_huge = (u32)h->h_small[4] <= HUGE_LIST_CAP ? (u32)h->h_small[4] : 0u;
+    h->ix.huge_at = n_huge ? huge_at : 0u;
     // worst case: every slice the batch may need, the tail a private chunk strands at each refill (< 1/8 of it), and
     // one partly used chunk per persistent wave
     if ((rc = ensure_arena(h, h->h_small[3] + h->h_small[3] / 7 + (u64)h->insert_waves * ARENA_CHUNK))) return rc;
@@ -564,6 +580,11 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
 #undef LAUNCH_INSERT_FAST
 #undef LAUNCH_INSERT
         if ((rc = launch_check(h, big ? "k_insert_big" : "k_insert"))) return rc;
+        if (n_huge) {
+            hipLaunchKernelGGL(k_insert_huge, dim3(std::min<u32>(n_huge, 256u)), dim3(HG_THREADS), 0, h->stream, P, src, (const PartDesc*)h->desc.p, (const u32*)h->huge.p + 1,
+                               (const u32*)h->huge.p, h->ix);
+            if ((rc = launch_check(h, "k_insert_huge"))) return rc;
+        }
     }
     h->nb_skmers += n_rec;
     h->dir_snapshot_valid = false;
@@ -1217,7 +1238,7 @@ int drain_profile(brisk_hip_index* h) {
 void free_all(brisk_hip_index* h) {
     hipStreamSynchronize(h->stream);  // nothing of ours may be in flight when the arena is unmapped
     auto fr = [](void* p) { if (p) hipFree(p); };
-    for (DevBuf* b : {&h->pend, &h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
+    for (DevBuf* b : {&h->huge, &h->pend, &h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
                       &h->lookup_buf})
         fr(b->p);
     fr(h->d_coef);

@@ -58,6 +58,7 @@ struct IndexDev {
     unsigned long long arena_cap;  // entries the arena can hold
     u32* err;                    // sticky violation bits: 1 scatter slot out of range, 2 arena exhausted, 4 chunk overflow
     u32 bits_check;              // few buckets (2b < 20): read a bucket-bitmap word before or-ing into it
+    u32 huge_at;                 // partitions of more k-mer instances than this are left to k_insert_huge (0: none are)
 };
 
 // k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
@@ -500,6 +501,11 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                 rn = load_part_recs(P, src, dn.part, dn.r_begin, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
             }
 
+            if (ix.huge_at && d.n_inst > ix.huge_at) {  // a block of 16 waves takes this one (k_insert_huge)
+                d = dn;
+                rr = rn;
+                continue;
+            }
             CNT(0, 1)
             const u32 part = d.part;
             u32 r_end = d.r_begin + d.n_rec;
@@ -913,5 +919,215 @@ __global__ void __launch_bounds__(256) k_stats(const DirEnt* __restrict__ dir, u
         unsigned long long m = s_c[0];
         for (int i = 1; i < 4; i++) m = s_c[i] > m ? s_c[i] : m;
         atomicMax(&out[2], m);
+    }
+}
+
+
+// ===========================================================================
+// k_insert_huge: one WORKGROUP of 16 waves per partition, for the partitions one wave must not be left alone with: a hot
+// minimizer (satellite repeats, poly-A) puts 10^5..10^6 distinct k-mers into ONE partition, which the wave-per-partition
+// kernels work off in chunks of 256 / 512 instances, every chunk streaming the partition's entries through its table --
+// entries x instances / 256 probes by 64 lanes while the rest of the device idles.  Here a chunk is 2048 instances in a
+// table shared by 1024 lanes: 8 times fewer passes over the entries, each 16 times as wide.  Same semantics as insert_body
+// (find-all then insert-missing, DenseMenuYo.hpp:248-310; counts wrap at 256); run-time geometry; classic and binned record
+// layouts.  Partitions are chosen by k_need (PartDesc::n_inst > IndexDev::huge_at); the wave kernels skip them.
+#define HG_THREADS 1024u
+#define HG_INST 2048u          // k-mer instances per chunk
+#define HG_TAB 4096u           // table slots
+#define HG_LIVE 0x80000000u    // s_cnt: the key owns a table slot (keys allocated by the losers of a CAS race stay dead)
+#define HG_EXIST 0x40000000u   // s_cnt: an existing entry has this key
+#define HG_MULT 0x3fffffffu
+__device__ __forceinline__ const u64* huge_rec(const BriskParams& P, const RecSrc& src, const PartDesc& d, u32 i) {  // record i of the partition (RecSrc)
+    if (!src.bin_cap) return src.rec + (u64)(d.r_begin + i) * P.stride;
+    return i < src.bin_cap ? src.rec + ((u64)d.part * src.bin_cap + i) * P.stride : src.ovf + ((u64)d.r_begin + i - src.bin_cap) * P.stride;
+}
+// inclusive prefix sum over the block's 1024 lanes (wave scan + the waves' totals through LDS); *total: the block's sum
+__device__ __forceinline__ u32 block_incl_scan(u32 v, u32* s_wsum, u32* total) {
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = __shfl_up(x, o, 64);
+        if ((int)lane >= o) x += y;
+    }
+    __syncthreads();  // s_wsum may still be read from the previous call
+    if (lane == 63) s_wsum[wid] = x;
+    __syncthreads();
+    u32 before = 0, all = 0;
+    for (u32 i = 0; i < HG_THREADS / 64; i++) {
+        const u32 c = s_wsum[i];
+        if (i < wid) before += c;
+        all += c;
+    }
+    *total = all;
+    return x + before;
+}
+__global__ void __launch_bounds__(HG_THREADS) k_insert_huge(BriskParams P, RecSrc src, const PartDesc* __restrict__ desc, const u32* __restrict__ huge_list,
+                                                            const u32* __restrict__ n_huge, IndexDev ix) {
+    __shared__ u64 s_key[2 * HG_INST];
+    __shared__ u32 s_tab[HG_TAB];
+    __shared__ u32 s_cnt[HG_INST];
+    __shared__ u32 s_pref[HG_THREADS + 1];
+    __shared__ u32 s_wsum[HG_THREADS / 64];
+    __shared__ u32 s_nkeys, s_bm[2], s_fail;
+    __shared__ unsigned long long s_noff;
+    const u32 tid = threadIdx.x;
+    const u32 kbits = 2 * P.kb + 6;
+    for (u32 hi = blockIdx.x; hi < *n_huge; hi += gridDim.x) {
+        const PartDesc d = desc[huge_list[hi]];
+        u32 n_exist = d.n_exist, cap = d.cap, inst_left = d.n_inst;
+        unsigned long long off = d.off, garbage = 0;
+        if (tid < 2) s_bm[tid] = 0;
+        if (tid == 0) s_fail = 0;
+        bool failed = false;
+        for (u32 rc = 0; rc < d.n_rec && !failed;) {
+            // ---- the chunk: the longest run of records (one per lane) with at most HG_INST instances
+            const u32 avail = min(d.n_rec - rc, HG_THREADS);
+            u32 my_n = 0;
+            if (tid < avail) my_n = hdr_n(huge_rec(P, src, d, rc + tid)[P.nw]);
+            u32 all;
+            const u32 x = block_incl_scan(my_n, s_wsum, &all);
+            s_pref[tid + 1] = x;
+            if (tid == 0) {
+                s_pref[0] = 0;
+                s_nkeys = 0;
+            }
+            for (u32 i = tid; i < HG_TAB; i += HG_THREADS) s_tab[i] = EMPTY_SLOT;
+            u32 nrec;
+            (void)block_incl_scan(tid < avail && x <= HG_INST ? 1u : 0u, s_wsum, &nrec);  // a prefix: >= 1 (a record has <= 255 instances)
+            __syncthreads();
+            const u32 ninst = s_pref[nrec];
+            // ---- expand and de-duplicate: every distinct key gets a slot in s_key / s_cnt and an entry in the table
+            for (u32 i = tid; i < ninst; i += HG_THREADS) {
+                u32 lo = 0, hi2 = nrec;  // the record r with s_pref[r] <= i < s_pref[r + 1]
+                while (hi2 - lo > 1) {
+                    const u32 mid = (lo + hi2) >> 1;
+                    if (s_pref[mid] <= i) lo = mid; else hi2 = mid;
+                }
+                const u64* c = huge_rec(P, src, d, rc + lo);
+                u64 w[5];
+                for (u32 q = 0; q < 5; q++) w[q] = q <= P.nw ? c[q] : 0;
+                const u64 hdr = w[P.nw];
+                const u32 j = i - s_pref[lo];
+                const u128x key = make_key(P, hdr_bucket(hdr), record_kmer(P, w, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+                const u32 mult = (hdr & HDR_HAS_MULT) ? (u32)(hdr >> 48) & 0xffu : 1u;
+                u32 h = hash_key32(key) & (HG_TAB - 1), mine = EMPTY_SLOT;
+                for (;;) {
+                    u32 v = s_tab[h];
+                    if (v == EMPTY_SLOT) {
+                        if (mine == EMPTY_SLOT) {
+                            mine = atomicAdd(&s_nkeys, 1u);
+                            s_key[2 * mine] = key.lo;
+                            s_key[2 * mine + 1] = key.hi;
+                            s_cnt[mine] = 0;
+                            __threadfence_block();  // the key is in place before the table points at it
+                        }
+                        v = atomicCAS(&s_tab[h], EMPTY_SLOT, mine);
+                        if (v == EMPTY_SLOT) {
+                            atomicAdd(&s_cnt[mine], mult | HG_LIVE);
+                            break;
+                        }
+                    }
+                    __threadfence_block();
+                    if (s_key[2 * v] == key.lo && s_key[2 * v + 1] == key.hi) {
+                        atomicAdd(&s_cnt[v], mult);
+                        break;
+                    }
+                    h = (h + 1) & (HG_TAB - 1);
+                }
+            }
+            __syncthreads();
+            const u32 nkeys = s_nkeys;
+            // ---- the partition's entries: the ones that are in the chunk take its multiplicity (mod 256)
+            for (u32 e = tid; e < n_exist; e += HG_THREADS) {
+                const u64 klo = ix.keys[2 * (off + e)], khi = ix.keys[2 * (off + e) + 1];
+                u32 h = hash_key32(mk128(klo, khi)) & (HG_TAB - 1);
+                for (;;) {
+                    const u32 v = s_tab[h];
+                    if (v == EMPTY_SLOT) break;
+                    if (s_key[2 * v] == klo && s_key[2 * v + 1] == khi) {
+                        const u32 m = atomicOr(&s_cnt[v], HG_EXIST) & HG_MULT;
+                        ix.counts[off + e] = (uint8_t)(ix.counts[off + e] + m);
+                        break;
+                    }
+                    h = (h + 1) & (HG_TAB - 1);
+                }
+            }
+            __syncthreads();
+            // ---- the new ones: counted, given room (the partition moves at most once per batch), appended
+            u32 mine_new = 0;
+            for (u32 q = tid; q < nkeys; q += HG_THREADS) {
+                const u32 cv = s_cnt[q];
+                mine_new += (cv & HG_LIVE) && !(cv & HG_EXIST) ? 1u : 0u;
+            }
+            u32 n_new;
+            (void)block_incl_scan(mine_new, s_wsum, &n_new);
+            inst_left -= ninst;
+            if (n_exist + n_new > cap) {
+                const unsigned long long want = grow_cap(n_exist + n_new + inst_left);
+                if (tid == 0) {
+                    const unsigned long long got = atomicAdd(ix.cursor, want);
+                    s_noff = got;
+                    if (got + want > ix.arena_cap) {  // must not happen (the host reserves the bound): drop, flag
+                        atomicOr(ix.err, 2u);
+                        s_fail = 1;
+                    }
+                }
+                __syncthreads();
+                if (s_fail) {
+                    failed = true;
+                    break;
+                }
+                const unsigned long long noff = s_noff;
+                for (u32 e = tid; e < n_exist; e += HG_THREADS) {
+                    ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
+                    ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (off + e) + 1];
+                    ix.counts[noff + e] = ix.counts[off + e];
+                }
+                garbage += cap;
+                cap = (u32)want;
+                off = noff;
+            }
+            u32 done = 0;  // new entries of the rounds before this one
+            for (u32 q0 = 0; q0 < nkeys; q0 += HG_THREADS) {
+                const u32 q = q0 + tid;
+                const u32 cv = q < nkeys ? s_cnt[q] : 0;
+                const bool is_new = (cv & HG_LIVE) && !(cv & HG_EXIST);
+                u32 round;
+                const u32 pos = block_incl_scan(is_new ? 1u : 0u, s_wsum, &round);
+                if (is_new) {
+                    const unsigned long long at = off + n_exist + done + pos - 1;
+                    const u64 klo = s_key[2 * q], khi = s_key[2 * q + 1];
+                    ix.keys[2 * at] = klo;
+                    ix.keys[2 * at + 1] = khi;
+                    ix.counts[at] = (uint8_t)(cv & HG_MULT);
+                    // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here), as insert_body has it
+                    const u32 bl = P.shift ? ((u32)shr128(mk128(klo, khi), kbits).lo & ((1u << P.shift) - 1)) : 0;
+                    const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;
+                    atomicOr(&s_bm[bb >> 5], 1u << (bb & 31));
+                }
+                done += round;
+            }
+            n_exist += n_new;
+            rc += nrec;
+            __syncthreads();  // the table and the key store are reused by the next chunk
+        }
+        __syncthreads();
+        if (tid == 0 && !failed) {
+            ix.dir[d.part] = DirEnt{off, n_exist, cap};
+            if (garbage) atomicAdd(&ix.stats[3], garbage);
+        }
+        if (P.shift <= 6 && tid < 2 && !failed) {  // bucket occupancy bits, as in insert_body's epilogue
+            const u32 mask = s_bm[tid];
+            const u32 nb = 1u << P.shift;
+            const u64 first = ((u64)d.part << P.shift) >> P.ext_bits;
+            if (mask) {
+                if (nb >= 32) {
+                    if (tid * 32 < nb) atomicOr(&ix.bucket_bits[(first >> 5) + tid], mask);
+                } else if (tid == 0) {
+                    atomicOr(&ix.bucket_bits[first >> 5], mask << (first & 31));
+                }
+            }
+        }
+        __syncthreads();
     }
 }

@@ -148,9 +148,11 @@ struct PartDesc {
 __device__ __forceinline__ u32 grow_cap(u32 n) { return n + (n >> 2) + 8; }
 // bin_cap > 0 (binned layout): n_rec comes from the histogram, r_begin is the partition's offset among the overflow
 // records (part_off then holds the prefix over the records beyond the bins; null when no partition overflowed)
+// huge (null: none): huge[0] counts, huge[1..] lists, the descriptors of partitions with more than huge_at k-mer instances (k_insert_huge)
 __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restrict__ hist, const u32* __restrict__ part_off,
                                               const u32* __restrict__ list, u32 n_list, const DirEnt* __restrict__ dir,
-                                              PartDesc* __restrict__ desc, unsigned long long* out, u32 bin_cap) {
+                                              PartDesc* __restrict__ desc, unsigned long long* out, u32 bin_cap, u32 huge_at = 0, u32* __restrict__ huge = nullptr,
+                                              u32 huge_cap = 0) {
     __shared__ unsigned long long s_sum[4];
     unsigned long long need = 0;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {  // grid-stride: few blocks, few atomics
@@ -170,6 +172,10 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
         d.cap = de.cap;
         d.off = de.off;
         desc[i] = d;
+        if (huge && d.n_inst > huge_at) {
+            const u32 at = atomicAdd(&huge[0], 1u);
+            if (at < huge_cap) huge[1 + at] = i;
+        }
         const u32 tot = d.n_exist + d.n_inst;
         if (tot > d.cap) need += grow_cap(tot);
     }

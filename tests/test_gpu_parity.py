@@ -166,7 +166,7 @@ def test_lookup_and_get(B, O):
 
 
 def test_kernel_variants_match_the_oracle(B):
-    """The layouts and kernel bodies small inputs never reach by themselves: records binned by the scan (bins of 2: nearly
+    """The layouts and kernel bodies small inputs never (or hardly ever) reach by themselves: records binned by the scan (bins of 2: nearly
     everything overflows into the classic scatter; bins of 64: nothing does), for the insert and for the get, the classic
     layout, and the run-time-geometry insert / query bodies.  One process per environment (tests/env_variant_worker.py)."""
     import os
@@ -174,7 +174,9 @@ def test_kernel_variants_match_the_oracle(B):
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_variant_worker.py")
     for extra in ({"BRISK_BINS": "2", "BRISK_QUERY_ENT": "256"}, {"BRISK_BINS": "64", "BRISK_QUERY_ENT": "128"}, {"BRISK_BINS": "0", "BRISK_DEFER": "0"},
-                  {"BRISK_INSERT_GENERIC": "1", "BRISK_QUERY_GENERIC": "1", "BRISK_BINS": "0"}):
+                  {"BRISK_INSERT_GENERIC": "1", "BRISK_QUERY_GENERIC": "1", "BRISK_BINS": "0"},
+                  # the workgroup-per-partition insert for every partition of more than 24 instances, classic and binned records
+                  {"BRISK_HUGE_AT": "24", "BRISK_BINS": "0"}, {"BRISK_HUGE_AT": "24", "BRISK_BINS": "2"}):
         env = dict(os.environ, **extra)
         p = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and p.stdout.strip().endswith("ok 12"), (extra, p.stdout[-2000:], p.stderr[-4000:])
