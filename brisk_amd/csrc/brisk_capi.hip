@@ -1055,10 +1055,16 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
     if (n_touched == 0) return BRISK_HIP_OK;
     if ((rc = ensure(h, h->desc, (size_t)n_touched * sizeof(PartDesc)))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_small + 3, 0, 8, h->stream));
+    // partitions whose entries x instances would keep one wave busy for long go to k_query_huge, a workgroup each
+    static const long hq_env = getenv("BRISK_HUGE_QUERY_AT") ? atol(getenv("BRISK_HUGE_QUERY_AT")) : -1;  // entries; tests: 0 sends (nearly) everything there
+    const u32 hq_at = hq_env >= 0 ? (u32)hq_env : 4096u;
+    if ((rc = ensure(h, h->huge, (size_t)(HUGE_LIST_CAP + 1) * 4))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->huge.p, 0, 4, h->stream));
     {
         ProfScope ps(h, S_TOUCHED);
         hipLaunchKernelGGL(k_need, dim3(std::min<u32>(nblocks(n_touched, 256), 2048)), dim3(256), 0, h->stream, h->d_hist, (bl && !n_move) ? (const u32*)nullptr : h->d_off,
-                           h->d_touched, n_touched, h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3, bl ? bl->bin_cap : 0u);
+                           h->d_touched, n_touched, h->ix.dir, (PartDesc*)h->desc.p, h->d_small + 3, bl ? bl->bin_cap : 0u, 0u, (u32*)h->huge.p, (u32)HUGE_LIST_CAP, hq_at,
+                           hq_env >= 0 ? 0ull : 1ull << 26);
         if (int lrc = launch_check(h, "k_need")) return lrc;
     }
     {
@@ -1099,8 +1105,12 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
                                (const PartDesc*)h->desc.p, n_touched, h->ix, d_sums, (u32*)(h->d_small + 6));
 #undef LAUNCH_QUERY_FAST
 #undef LAUNCH_QUERY_FAST_ENT
+        if (int lrc = launch_check(h, "k_query")) return lrc;
+        // the listed partitions (none, as a rule: the kernel reads the list's length on the device and returns)
+        hipLaunchKernelGGL(k_query_huge, dim3(256), dim3(HG_THREADS), 0, h->stream, P, src, tags_binned, (const u32*)h->tags_b.p, (const PartDesc*)h->desc.p, (const u32*)h->huge.p + 1,
+                           (const u32*)h->huge.p, h->ix, d_sums);
     }
-    return launch_check(h, "k_query");
+    return launch_check(h, "k_query_huge");
 }
 
 // Host ASCII -> packed 2-bit stream on the device.  The caller's memory is pageable: a plain hipMemcpy moves it at

@@ -146,13 +146,15 @@ struct PartDesc {
     unsigned long long off;
 };
 __device__ __forceinline__ u32 grow_cap(u32 n) { return n + (n >> 2) + 8; }
+#define PART_HUGE 0x80000000u   // PartDesc::n_exist of a query batch: k_query_huge takes this partition
 // bin_cap > 0 (binned layout): n_rec comes from the histogram, r_begin is the partition's offset among the overflow
 // records (part_off then holds the prefix over the records beyond the bins; null when no partition overflowed)
-// huge (null: none): huge[0] counts, huge[1..] lists, the descriptors of partitions with more than huge_at k-mer instances (k_insert_huge)
+// huge (null: none): huge[0] counts, huge[1..] lists, the descriptors of partitions with more than huge_at k-mer instances (k_insert_huge) or,
+// huge_at == 0, with more than huge_exist_at entries (k_query_huge)
 __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restrict__ hist, const u32* __restrict__ part_off,
                                               const u32* __restrict__ list, u32 n_list, const DirEnt* __restrict__ dir,
                                               PartDesc* __restrict__ desc, unsigned long long* out, u32 bin_cap, u32 huge_at = 0, u32* __restrict__ huge = nullptr,
-                                              u32 huge_cap = 0) {
+                                              u32 huge_cap = 0, u32 huge_exist_at = 0, unsigned long long huge_work = 0) {
     __shared__ unsigned long long s_sum[4];
     unsigned long long need = 0;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {  // grid-stride: few blocks, few atomics
@@ -171,12 +173,23 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
         d.n_exist = de.cnt;
         d.cap = de.cap;
         d.off = de.off;
-        desc[i] = d;
-        if (huge && d.n_inst > huge_at) {
-            const u32 at = atomicAdd(&huge[0], 1u);
-            if (at < huge_cap) huge[1 + at] = i;
-        }
         const u32 tot = d.n_exist + d.n_inst;
+        if (huge) {
+            if (huge_at) {  // insert: many instances (the host diverts none if the list overflows)
+                if (d.n_inst > huge_at) {
+                    const u32 at = atomicAdd(&huge[0], 1u);
+                    if (at < huge_cap) huge[1 + at] = i;
+                }
+            } else if (d.n_exist > huge_exist_at && (unsigned long long)d.n_exist * d.n_inst > huge_work) {
+                // query: entries x instances is what a wave would have to do; a listed partition carries PART_HUGE in n_exist
+                const u32 at = atomicAdd(&huge[0], 1u);
+                if (at < huge_cap) {
+                    huge[1 + at] = i;
+                    d.n_exist |= PART_HUGE;
+                }
+            }
+        }
+        desc[i] = d;
         if (tot > d.cap) need += grow_cap(tot);
     }
     for (int o = 32; o > 0; o >>= 1) need += __shfl_down(need, o, 64);

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(64) k_query(BriskParams P, const u64* __restri
         for (u32 t = t0; t < t_end; t++) {
             const PartDesc d = desc[t];
             if (d.n_exist == 0) continue;  // nothing to find in an empty partition
+            if (d.n_exist & PART_HUGE) continue;  // k_query_huge takes it
             const u32 r_end = d.r_begin + d.n_rec;
             for (u32 rc = d.r_begin; rc < r_end;) {
                 const u32 avail = min(r_end - rc, (u32)WI_MAX_REC);
@@ -161,6 +162,7 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, c
         for (u32 ti = 0; ti < t_n; ti++) {
             const PartDesc d = batch_desc(bd, ti);
             if (d.n_exist == 0) continue;  // nothing to find in an empty partition
+            if (d.n_exist & PART_HUGE) continue;  // k_query_huge takes it
             const u32 r_end = d.r_begin + d.n_rec;
             for (u32 ec = 0; ec < d.n_exist; ec += QF_ENT) {
                 const u32 ne = min(d.n_exist - ec, QF_ENT);
@@ -285,6 +287,84 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, c
                         }
                     }
                     rc += nrec;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_query_huge: a workgroup of 16 waves per partition of very many entries (a hot minimizer, see k_insert_huge): the wave
+// kernels walk all of a partition's records once per table chunk of 128 / 256 entries -- entries / 256 x instances probes by
+// one wave.  Here the table holds 2048 entries and 1024 lanes probe it.  Run-time geometry; classic and binned records.
+#define HQ_LIST_CAP 65536u   // listed partitions per batch (the rest stay with the wave kernels)
+#define HQ_ENT 2048u
+#define HQ_TAB 4096u
+__global__ void __launch_bounds__(HG_THREADS) k_query_huge(BriskParams P, RecSrc src, const u32* __restrict__ tags_binned, const u32* __restrict__ tags,
+                                                           const PartDesc* __restrict__ desc, const u32* __restrict__ huge_list, const u32* __restrict__ n_huge, IndexDev ix,
+                                                           unsigned long long* __restrict__ per_read_sum) {
+    __shared__ u64 s_ekey[2 * HQ_ENT];
+    __shared__ u32 s_tab[HQ_TAB];
+    __shared__ u32 s_pref[HG_THREADS + 1];
+    __shared__ u32 s_rsum[HG_THREADS];
+    __shared__ u32 s_wsum[HG_THREADS / 64];
+    const u32 tid = threadIdx.x;
+    for (u32 hi = blockIdx.x; hi < min(*n_huge, (u32)HQ_LIST_CAP); hi += gridDim.x) {
+        PartDesc d = desc[huge_list[hi]];
+        d.n_exist &= ~PART_HUGE;
+        for (u32 ec = 0; ec < d.n_exist; ec += HQ_ENT) {
+            const u32 ne = min(d.n_exist - ec, HQ_ENT);
+            __syncthreads();  // the previous chunk's probes are done
+            for (u32 i = tid; i < HQ_TAB; i += HG_THREADS) s_tab[i] = EMPTY_SLOT;
+            __syncthreads();
+            for (u32 e = tid; e < ne; e += HG_THREADS) {
+                const u64 klo = ix.keys[2 * (d.off + ec + e)], khi = ix.keys[2 * (d.off + ec + e) + 1];
+                s_ekey[2 * e] = klo;
+                s_ekey[2 * e + 1] = khi;
+                const u32 word = e | ((u32)ix.counts[d.off + ec + e] << 16);  // entry of the chunk | its count
+                u32 h = hash_key32(mk128(klo, khi)) & (HQ_TAB - 1);
+                while (atomicCAS(&s_tab[h], EMPTY_SLOT, word) != EMPTY_SLOT) h = (h + 1) & (HQ_TAB - 1);
+            }
+            for (u32 rc = 0; rc < d.n_rec; rc += HG_THREADS) {  // the partition's records, one per lane; their instances spread over the lanes
+                const u32 avail = min(d.n_rec - rc, HG_THREADS);
+                const u32 my_n = tid < avail ? hdr_n(huge_rec(P, src, d, rc + tid)[P.nw]) : 0;
+                u32 ninst;
+                const u32 x = block_incl_scan(my_n, s_wsum, &ninst);
+                s_pref[tid + 1] = x;
+                if (tid == 0) s_pref[0] = 0;
+                s_rsum[tid] = 0;
+                __syncthreads();  // also: the table is complete
+                for (u32 i = tid; i < ninst; i += HG_THREADS) {
+                    u32 lo = 0, hi2 = avail;  // the record r with s_pref[r] <= i < s_pref[r + 1]
+                    while (hi2 - lo > 1) {
+                        const u32 mid = (lo + hi2) >> 1;
+                        if (s_pref[mid] <= i) lo = mid; else hi2 = mid;
+                    }
+                    const u64* c = huge_rec(P, src, d, rc + lo);
+                    u64 w[5];
+                    for (u32 q = 0; q < 5; q++) w[q] = q <= P.nw ? c[q] : 0;
+                    const u64 hdr = w[P.nw];
+                    const u32 j = i - s_pref[lo];
+                    const u128x key = make_key(P, hdr_bucket(hdr), record_kmer(P, w, hdr_n(hdr), j), hdr_idx0(hdr) + j);
+                    u32 h = hash_key32(key) & (HQ_TAB - 1);
+                    for (;;) {
+                        const u32 v = s_tab[h];
+                        if (v == EMPTY_SLOT) break;
+                        const u32 e = v & 0xffffu;
+                        if (s_ekey[2 * e] == key.lo && s_ekey[2 * e + 1] == key.hi) {
+                            if (v >> 16) atomicAdd(&s_rsum[lo], v >> 16);
+                            break;
+                        }
+                        h = (h + 1) & (HQ_TAB - 1);
+                    }
+                }
+                __syncthreads();
+                if (tid < avail && s_rsum[tid]) {
+                    const u32 i = rc + tid;
+                    u32 tag;
+                    if (!src.bin_cap) tag = tags[d.r_begin + i];
+                    else tag = i < src.bin_cap ? tags_binned[(u64)d.part * src.bin_cap + i] : tags[d.r_begin + i - src.bin_cap];
+                    atomicAdd(&per_read_sum[tag], (unsigned long long)s_rsum[tid]);
                 }
             }
         }

@@ -175,8 +175,8 @@ def test_kernel_variants_match_the_oracle(B):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_variant_worker.py")
     for extra in ({"BRISK_BINS": "2", "BRISK_QUERY_ENT": "256"}, {"BRISK_BINS": "64", "BRISK_QUERY_ENT": "128"}, {"BRISK_BINS": "0", "BRISK_DEFER": "0"},
                   {"BRISK_INSERT_GENERIC": "1", "BRISK_QUERY_GENERIC": "1", "BRISK_BINS": "0"},
-                  # the workgroup-per-partition insert for every partition of more than 24 instances, classic and binned records
-                  {"BRISK_HUGE_AT": "24", "BRISK_BINS": "0"}, {"BRISK_HUGE_AT": "24", "BRISK_BINS": "2"}):
+                  # the workgroup-per-partition insert / query for every partition of more than 24 instances / 8 (0) entries, classic and binned records
+                  {"BRISK_HUGE_AT": "24", "BRISK_BINS": "0", "BRISK_HUGE_QUERY_AT": "8"}, {"BRISK_HUGE_AT": "24", "BRISK_BINS": "2", "BRISK_HUGE_QUERY_AT": "0"}):
         env = dict(os.environ, **extra)
         p = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and p.stdout.strip().endswith("ok 12"), (extra, p.stdout[-2000:], p.stderr[-4000:])

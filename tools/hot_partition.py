@@ -18,4 +18,6 @@ for rep in range(2):
     ix.clear()
     t0 = time.perf_counter(); ix.insert_reads(reads); st = ix.stats(); dt = time.perf_counter() - t0
     print("HUGE_AT=%s %d reads: %.1f ms  entries %d, largest partition %d" % (os.environ.get("BRISK_HUGE_AT", "default"), n, dt * 1e3, st["nb_kmers"], st["largest_bucket"]), flush=True)
+t0 = time.perf_counter(); sums = ix.get_reads(reads); dt = time.perf_counter() - t0
+print("get of the same reads: %.1f ms, sum %d" % (dt * 1e3, int(sums.sum())), flush=True)
 print("checksum", ix.checksum())
