@@ -52,4 +52,11 @@ for k, m, b in ((63, 21, 14), (31, 15, 14), (31, 11, 11), (47, 15, 10)):
         assert np.array_equal(sums.cpu().numpy().astype(np.uint64), want_q), (k, m, b, "get_packed")
         assert np.array_equal(ix.get_reads(queries), want_q), (k, m, b, "get_reads")
         checks += 3
+        if (k, m, b) in ((63, 21, 14), (31, 11, 11)):  # re-bucketing: records that carry multiplicities (tests/test_reallocate.py)
+            from test_reallocate import _expected, _lines_to_counter
+            before = oracle.multiset_lines(*ix.enumerate(), k)
+            with brisk_amd.BriskHip(k, m + 2, b + 2) as new:
+                ix.reallocate_into(new)
+                after = oracle.multiset_lines(*new.enumerate(), k)
+            assert _lines_to_counter(after) == _expected(O, before, k, m + 2), (k, m, b, "reallocate")
 print("ok", checks)
