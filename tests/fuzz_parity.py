@@ -8,6 +8,7 @@ import brisk_amd, oracle
 oracle.build(ref=False)
 O = oracle.Oracle()
 budget, seed = float(sys.argv[1]), int(sys.argv[2])
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # replay: run just this case of the seed's sequence
 rng = random.Random(seed)
 t_end = time.time() + budget
 n_ok = 0
@@ -34,7 +35,9 @@ def rand_reads():
         out += ["A" * rng.randint(1, 300), "T" * 200, "AC" * 100]
     return out
 
+case = -1
 while time.time() < t_end:
+    case += 1
     k = rng.randint(12, 63)
     m = rng.choice([x for x in range(5, min(k - 1, 31) + 1, 2)])
     b = rng.randint(1, min(m, 14))
@@ -42,26 +45,49 @@ while time.time() < t_end:
     if 2 * (k - b) + 6 > 128:
         continue  # outside the library's envelope (EUNSUPPORTED): the entry key [compacted k-mer | idx'] must fit 128 bits
     reads = rand_reads()
+    immediate, splits, peeks = rng.random() < 0.3, [rng.choice([1, 7, 64, 300, 10**9]) for _ in range(4000)], [rng.random() < 0.1 for _ in range(4000)]
+    qsel = sorted(rng.sample(range(len(reads)), min(len(reads), 60)))
+    if only >= 0 and case != only:
+        if case > only:
+            break
+        continue
     want = O.count(reads, k, m, b)
-    q = [reads[i] for i in sorted(rng.sample(range(len(reads)), min(len(reads), 60)))] + ["A" * 150]
+    q = [reads[i] for i in qsel] + ["A" * 150]
     flat, offs = oracle.pack_reads(reads)
     h = O.index_new(k, m, b); O.index_insert_reads(h, flat, offs)
     qf, qo = oracle.pack_reads(q); want_q = O.index_query_reads(h, qf, qo); O.index_free(h)
     try:
-        with brisk_amd.BriskHip(k, m, b, part_bits=pb, immediate_inserts=rng.random() < 0.3) as ix:
-            i = 0
+        with brisk_amd.BriskHip(k, m, b, part_bits=pb, immediate_inserts=immediate) as ix:
+            i = step = 0
             while i < len(reads):
-                n = rng.choice([1, 7, 64, 300, len(reads)])
+                n = splits[step % len(splits)]
                 ix.insert_reads(reads[i:i + n]); i += n
-                if rng.random() < 0.1:
+                if peeks[step % len(peeks)]:
                     ix.stats()
+                step += 1
             st = ix.stats()
             got = (sorted(oracle.multiset_lines(*ix.enumerate(), k)), st["nb_kmers"], st["nb_buckets"])
-            assert got == want, "index differs"
+            if got != want:
+                import collections
+                ca, cb = collections.Counter(got[0]), collections.Counter(want[0])
+                extra, missing = list((ca - cb).items()), list((cb - ca).items())
+                wk = collections.defaultdict(list)
+                for line in want[0]:
+                    w_ = line.split()
+                    wk[w_[0]].append((w_[1], w_[2]))
+                comp = str.maketrans("ACGT", "TGCA")
+                notes = []
+                for line, _ in extra[:40]:
+                    km, idx, cnt = line.split()
+                    where = [ri for ri, r in enumerate(reads) if km in r.upper() or km[::-1].translate(comp) in r.upper()][:4]
+                    notes.append((km[:12] + "..", idx, cnt, "oracle has this k-mer as", wk.get(km), "reads", where))
+                again = sorted(oracle.multiset_lines(*ix.enumerate(), k))
+                raise AssertionError("index differs: nb_kmers %d/%d nb_buckets %d/%d; %d extra, %d missing; enumerate stable: %s; immediate=%s splits=%s\n  extra: %s\n  missing: %s" % (
+                    got[1], want[1], got[2], want[2], len(extra), len(missing), again == got[0], immediate, splits[:8], notes, missing[:40]))
             assert np.array_equal(ix.get_reads(q), want_q), "get differs"
             ix.sync()
     except Exception as e:
-        print("FAIL", dict(k=k, m=m, b=b, pb=pb, n=len(reads), seed=seed), repr(e)[:300], flush=True)
+        print("FAIL", dict(case=case, k=k, m=m, b=b, pb=pb, n=len(reads), seed=seed, immediate=immediate), repr(e)[:6000], flush=True)
         sys.exit(1)
     n_ok += 1
     if n_ok % 20 == 0:
