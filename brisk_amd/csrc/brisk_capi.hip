@@ -607,8 +607,8 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     } else {
         const u32 bt = h->scan_waves * 64;
         const dim3 grid(nblocks(n_items, bt)), block(bt);
-        // instantiations: chunk-table count nch = ceil(m/4) (6: m 21..23, 4: m 13..15, 3: m 9..11, else generic) x mode x
-        // {k and m compile-time for the two common parameter sets, or from P}
+        // instantiations: {k and m compile-time for the common parameter sets (the class tables' layout folds into the
+        // instructions), or from P with the chunk count unrolled (4: m 17..21, 3: m 12..16, 2: m 7..11; else a loop)} x mode
 #define LAUNCH_SCAN2(NCH, MODE, KK, MM) \
     hipLaunchKernelGGL((k_scan2<NCH, MODE, KK, MM>), grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, cc)
 #define LAUNCH_SCAN2_MODES(NCH, KK, MM)                    \
@@ -618,12 +618,12 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
         else LAUNCH_SCAN2(NCH, 0, KK, MM);                 \
     }
         const u32 k = h->P.k, m = h->P.m;
-        if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(6, 63, 21)
-        else if (k == 31 && m == 15) LAUNCH_SCAN2_MODES(4, 31, 15)  // the reference's default parameters (apps/counter.cpp:355)
-        else if (k == 31 && m == 11) LAUNCH_SCAN2_MODES(3, 31, 11)
-        else if (h->scfg.nch == 6) LAUNCH_SCAN2_MODES(6, 0, 0)
+        if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(0, 63, 21)
+        else if (k == 31 && m == 15) LAUNCH_SCAN2_MODES(0, 31, 15)  // the reference's default parameters (apps/counter.cpp:355)
+        else if (k == 31 && m == 11) LAUNCH_SCAN2_MODES(0, 31, 11)
         else if (h->scfg.nch == 4) LAUNCH_SCAN2_MODES(4, 0, 0)
         else if (h->scfg.nch == 3) LAUNCH_SCAN2_MODES(3, 0, 0)
+        else if (h->scfg.nch == 2) LAUNCH_SCAN2_MODES(2, 0, 0)
         else LAUNCH_SCAN2_MODES(0, 0, 0)
 #undef LAUNCH_SCAN2_MODES
 #undef LAUNCH_SCAN2
@@ -1368,37 +1368,47 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMemsetAsync(h->d_coef, 0, 128 * sizeof(double), h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_coef, coef_table, 4 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
         {
-            // decycling chunk tables (host, from the caller's libm table): 4 nts per chunk, both sums of a chunk in one u64.
+            // decycling chunk tables (host, from the caller's libm table): cls_nch(m) chunks of cls_width(m, c) nts, both sums
+            // of a chunk in one u64 (layout and decoding: decy_class_fast in brisk_scan.hip).
             // R(x)      = sum_{i=0}^{m-2} coef[4(m-1-i) + nt_i(x)]          (Decycling.cpp:17-24)
             // R(rot(x)) = sum_{i=1}^{m-1} coef[4(m-i)   + nt_i(x)]          (rot: Decycling.cpp:41)
-            // low word: the chunk's share of R, in units of 2^-24, + CLS_BIAS; high word: its share of R(rot), two's complement
+            // word = a + b * 2^32 as one signed 64-bit integer, a / b = the chunk's share of R / R(rot) in units of 2^-24
             ScanCfg& c = h->scfg;
             c.nlow = std::min<u32>(32, k);
             c.nlow1 = std::min<u32>(32, k - 1);
-            c.nch = (m + 3) / 4;
-            c.qcap = 320;  // > 4 super-k-mers per lane before a mid-read flush
-            if (const char* e = getenv("BRISK_SCAN_QCAP")) c.qcap = (u32)std::max(128, atoi(e));
-            const u32 n_tab = 128 + c.nch * 256;
+            c.nch = cls_nch(m);
+            c.qcap = 320;  // > 4 super-k-mers per lane before a mid-read flush (less where the tables need the LDS, below)
+            if (c.nch > CLS_MAX_CHUNKS) return fail(h, BRISK_HIP_EUNSUPPORTED, "minimizer too long for the class tables");
+            const u32 n_tab = 128 + cls_base(m, c.nch);
+            c.n_tab = n_tab;
             std::vector<double> tabs(n_tab, 0.0);
             for (u32 i = 0; i < 4u * m; i++) tabs[i] = coef_table[i];
-            for (u32 ch = 0; ch < c.nch; ch++)
-                for (u32 v = 0; v < 256; v++) {
+            for (u32 ch = 0; ch < c.nch; ch++) {
+                const u32 off = cls_off(m, ch), wd = cls_width(m, ch), base = cls_base(m, ch);
+                c.chunk[ch] = (2 * off) | ((2 * wd) << 6) | (base << 10);
+                for (u32 v = 0; v < (1u << (2 * wd)); v++) {
                     double a = 0.0, bsum = 0.0;
-                    for (u32 i = 4 * ch; i < 4 * ch + 4 && i < m; i++) {
-                        const u32 nt = (v >> (2 * (i - 4 * ch))) & 3;
+                    for (u32 i = off; i < off + wd; i++) {
+                        const u32 nt = (v >> (2 * (i - off))) & 3;
                         if (i + 1 < m) a += coef_table[4 * (m - 1 - i) + nt];
                         if (i >= 1) bsum += coef_table[4 * (m - i) + nt];
                     }
                     const int64_t af = llround(std::ldexp(a, 24)), bf = llround(std::ldexp(bsum, 24));
-                    const u64 word = (u64)(u32)(af + (int64_t)CLS_BIAS) | ((u64)(u32)(int32_t)bf << 32);
-                    memcpy(&tabs[128 + ch * 256 + v], &word, 8);
+                    const u64 word = (u64)(af + bf * (int64_t(1) << 32));
+                    memcpy(&tabs[128 + base + v], &word, 8);
                 }
+            }
             HIPCHK(h, hipMalloc((void**)&h->d_tabs, n_tab * sizeof(double)));
             HIPCHK(h, hipMemcpyAsync(h->d_tabs, tabs.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             // LDS: the class tables once per block, an emit queue per wave.  Eight waves per block, two blocks per CU.
-            const size_t per_wave = (size_t)(c.qcap + 96) * 8, fixed = (size_t)(n_tab + 9) * 8;  // queue + the lanes' read starts and tags
+            const size_t fixed = (size_t)(n_tab + 9) * 8;
             const size_t lds_max = 160 * 1024;
+            // big tables (m = 21: 57 KB): shorter queues rather than one block per CU (measured at m = 21, per 50 M reads:
+            // qcap 224 31.2 ms, 256 31.8, 192 32.4; one 16-wave block with qcap 320 43.9)
+            while (c.qcap > 224 && 2 * (fixed + 8 * (size_t)(c.qcap + 96) * 8) > lds_max - 4096) c.qcap -= 32;
+            if (const char* e = getenv("BRISK_SCAN_QCAP")) c.qcap = (u32)std::max(128, atoi(e));
+            const size_t per_wave = (size_t)(c.qcap + 96) * 8;  // queue + the lanes' read starts and tags
             u32 wv = 8;  // 2 blocks per CU, 4 waves per SIMD; block sizes that are not a multiple of 4 waves place badly
             if (2 * (fixed + wv * per_wave) > lds_max) wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);  // big m: one block per CU
             if (const char* e = getenv("BRISK_SCAN_WAVES")) wv = (u32)std::min(16, std::max(1, atoi(e)));
@@ -1409,7 +1419,8 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             if (h->scan_lds > lds_attr) {
                 lds_attr = h->scan_lds;
 #define SCAN2_FNS(NCH, KK, MM) (const void*)k_scan2<NCH, 0, KK, MM>, (const void*)k_scan2<NCH, 1, KK, MM>, (const void*)k_scan2<NCH, 2, KK, MM>
-                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(6, 0, 0), SCAN2_FNS(3, 31, 11), SCAN2_FNS(4, 31, 15), SCAN2_FNS(6, 63, 21)};
+                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(2, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(0, 31, 11), SCAN2_FNS(0, 31, 15), SCAN2_FNS(0, 63, 21),
+                                     (const void*)k_debug_keys};
 #undef SCAN2_FNS
                 for (const void* fn : fns) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
             }
@@ -2216,8 +2227,8 @@ BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mme
     u64* d_x = (u64*)h->lookup_buf.p;
     u64* d_k = d_x + n;
     HIPCHK(h, hipMemcpyAsync(d_x, mmers, n * 8, hipMemcpyHostToDevice, h->stream));
-    const size_t lds = (size_t)(128 + h->scfg.nch * 256) * 8;
-    hipLaunchKernelGGL(k_debug_keys, dim3(nblocks(n, 256)), dim3(256), lds, h->stream, h->P, h->scfg.nch, h->d_tabs, d_x, n, exact, d_k);
+    const size_t lds = (size_t)h->scfg.n_tab * 8;
+    hipLaunchKernelGGL(k_debug_keys, dim3(nblocks(n, 256)), dim3(256), lds, h->stream, h->P, h->scfg, h->d_tabs, d_x, n, exact, d_k);
     if ((rc = launch_check(h, "k_debug_keys"))) return rc;
     HIPCHK(h, hipMemcpyAsync(keys, d_k, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

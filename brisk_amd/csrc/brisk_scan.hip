@@ -350,52 +350,100 @@ __device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1u
 //     k-mers per round, using the closed form of the tie rules (first and last position of
 //     the minimum key);
 //   * closed super-k-mers are queued in LDS and turned into records by full waves.
+// ---- layout of the decycling chunk tables (shared by the host builder in brisk_capi.hip and the kernels) ----------------
+// An m-mer is cut into L = ceil((m-1)/5) chunks of 5 nts (one of 6 where m = 5L+1; fewer nts where m is small), low nts
+// first: m = 21 -> [6,5,5,5], 15 -> [5,5,5], 11 -> [6,5].  A look-up costs the same issue slots whatever its table's size
+// (tools/valu_rates.hip: a random ds_read_b64 with its address arithmetic ~26 cycles per wave against ~4.3 for a vector
+// instruction), so fewer, larger tables are cheaper: 4 look-ups instead of 6 at m = 21 -- for 57 KB of LDS instead of
+// 12, which is as far as it goes: two 8-wave blocks per CU must still fit with their emit queues (ONE 16-wave block per CU
+// ran the scan at 43.9 ms against 31.2: a block waits for its slowest wave with nothing else resident).  So the 6-nt chunk
+// is used up to L = 4 only (m = 31 -> [5,5,5,4,4,4,4]).  (-DBRISK_CLS_W4: 4-nt chunks, for A/B.)
+__host__ __device__ constexpr u32 cls_nch(u32 m) {
+#ifdef BRISK_CLS_W4
+    return (m + 3) / 4;
+#else
+    return m <= 6 ? 1u : (m + 3) / 5 + (m > 21 && m % 5 == 1 ? 1u : 0u);
+#endif
+}
+__host__ __device__ constexpr u32 cls_width(u32 m, u32 c) {  // nts in chunk c
+#ifdef BRISK_CLS_W4
+    return m - 4 * c < 4 ? m - 4 * c : 4u;
+#else
+    return m / cls_nch(m) + (c < m % cls_nch(m) ? 1u : 0u);
+#endif
+}
+__host__ __device__ constexpr u32 cls_off(u32 m, u32 c) {  // first nt of chunk c
+    u32 o = 0;
+    for (u32 j = 0; j < c; j++) o += cls_width(m, j);
+    return o;
+}
+__host__ __device__ constexpr u32 cls_base(u32 m, u32 c) {  // first table entry of chunk c; c = cls_nch(m): entries in all
+    u32 b = 0;
+    for (u32 j = 0; j < c; j++) b += 1u << (2 * cls_width(m, j));
+    return b;
+}
+#define CLS_MAX_CHUNKS 8
+
 struct ScanCfg {
     u32 nlow;     // nts of a k-mer that get_minimizer sees: min(32, k)   (F2)
     u32 nlow1;    // same for the (k-1)-mer
-    u32 nch;      // 4-nt chunks of an m-mer: ceil(m/4)
+    u32 nch;      // chunks of an m-mer: cls_nch(m)
     u32 qcap;     // emit queue entries per wave
+    u32 n_tab;    // doubles staged to LDS: coef[128] + the chunk tables
+    u32 chunk[CLS_MAX_CHUNKS];  // run-time layout for the generic kernels: first bit (6 b) | bits (4 b) << 6 | first entry << 10
 };
 
-// Decycling class from packed fixed-point chunk tables.  tabs[c * 256 + v] (one u64 per 4-nt chunk value) holds the
-// chunk's share of R(x) in its low word -- scaled by 2^24, biased by CLS_BIAS so that the low words of a whole sum
-// never carry -- and its share of R(rot(x)) in the high word (two's complement): ceil(m/4) look-ups and as many 64-bit
-// adds give both sums.  Every table word is rounded to a unit of 2^-24 (<= 0.5 unit of error each, <= 4 units per sum
-// for m <= 31; the reference's own FP64 fold is within 1e-5 unit of the exact value), eps = 1e-6 is 16.78 units: a sum
-// >= 21 is certainly > eps, a sum <= 12 certainly < eps, anything in [13, 20] (either sign) is decided by the exact
-// FP64 fold in the reference's order (decy_class).  Host side: build_class_tables in brisk_capi.hip.
-#define CLS_BIAS (1u << 28)
+// Decycling class from packed fixed-point chunk tables.  tabs[base_c + v] (one u64 per value v of chunk c) is the 64-bit
+// integer a + b * 2^32: a = the chunk's share of R(x), b = its share of R(rot(x)), both signed, in units of 2^-24.  The sum
+// of an m-mer's words is A + B * 2^32 with the whole sums A, B (|A|, |B| < 2^30): one look-up and one 64-bit add per chunk
+// give both.  Every a and b is rounded to a unit (<= 0.5 unit of error each, <= 4 units per sum for up to 8 chunks; the
+// reference's own FP64 fold is within 1e-5 unit of the exact value), eps = 1e-6 is 16.78 units: a sum >= 21 is certainly
+// > eps, a sum <= 12 certainly < eps, anything in [13, 20] (either sign) is decided by the exact FP64 fold in the
+// reference's order (decy_class).  Host side: brisk_hip_create in brisk_capi.hip.
 #define CLS_HI 21
 #define CLS_LO 12
-template <int NCH>  // NCH > 0: compile-time chunk count (unrolled look-ups); 0: runtime nch
-__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, u32 nch, const u64* tabs, const double* coef) {
-    u64 acc = tabs[(u32)x & 255];
-    if (NCH > 0) {
+// NCH > 0: compile-time chunk count (unrolled look-ups); MM > 0: compile-time m, the whole layout folds into the instructions
+template <int NCH, int MM>
+__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg, const u64* tabs, const double* coef) {
+    u64 acc;
+    if (MM > 0) {
+        constexpr u32 mm = MM > 0 ? (u32)MM : 1u;
+        acc = tabs[(u32)x & ((1u << (2 * cls_width(mm, 0))) - 1)];
 #pragma unroll
-        for (int c = 1; c < NCH; c++) acc += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+        for (u32 c = 1; c < cls_nch(mm); c++) acc += tabs[cls_base(mm, c) + ((u32)(x >> (2 * cls_off(mm, c))) & ((1u << (2 * cls_width(mm, c))) - 1))];
+    } else if (NCH > 0) {
+        acc = tabs[(u32)x & ((1u << ((cfg.chunk[0] >> 6) & 15)) - 1)];
+#pragma unroll
+        for (int c = 1; c < NCH; c++) {
+            const u32 d = cfg.chunk[c];
+            acc += tabs[(d >> 10) + ((u32)(x >> (d & 63)) & ((1u << ((d >> 6) & 15)) - 1))];
+        }
     } else {
-        for (u32 c = 1; c < nch; c++) acc += tabs[c * 256 + (u32)((x >> (8 * c)) & 255)];
+        acc = tabs[(u32)x & ((1u << ((cfg.chunk[0] >> 6) & 15)) - 1)];
+        for (u32 c = 1; c < cfg.nch; c++) {
+            const u32 d = cfg.chunk[c];
+            acc += tabs[(d >> 10) + ((u32)(x >> (d & 63)) & ((1u << ((d >> 6) & 15)) - 1))];
+        }
     }
-    const int a = (int)((u32)acc - (NCH > 0 ? (u32)NCH : nch) * CLS_BIAS), b = (int)(u32)(acc >> 32);
+    const int a = (int)(u32)acc, b = (int)(u32)(acc >> 32) - (a >> 31);  // the high word holds B + floor(A / 2^32)
     const u32 ua = (u32)(a < 0 ? -a : a), ub = (u32)(b < 0 ? -b : b);
     if (ua - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2) || ub - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2)) return decy_class(x, m, coef);
     const bool c0 = a >= CLS_HI && b <= CLS_LO, c1 = a <= -CLS_HI && b >= -CLS_LO;
     return c0 ? 0u : c1 ? 1u : 2u;
 }
-template <int NCH = 0>
-__device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, u32 nch, const u64* tabs, const double* coef) {
-    return ((u64)decy_class_fast<NCH>(x, m, nch, tabs, coef) << 62) + mix2m(x, M);
+template <int NCH = 0, int MM = 0>
+__device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, const ScanCfg& cfg, const u64* tabs, const double* coef) {
+    return ((u64)decy_class_fast<NCH, MM>(x, m, cfg, tabs, coef) << 62) + mix2m(x, M);
 }
 
-__global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, u32 nch, const double* __restrict__ g_tabs, const u64* __restrict__ x, u64 n,
+__global__ void __launch_bounds__(256) k_debug_keys(BriskParams P, ScanCfg cfg, const double* __restrict__ g_tabs, const u64* __restrict__ x, u64 n,
                                                     int exact, u64* __restrict__ out) {
     extern __shared__ double smem_d[];
-    const u32 n_tab = 128 + nch * 256;
-    for (u32 i = threadIdx.x; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
+    for (u32 i = threadIdx.x; i < cfg.n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
     __syncthreads();
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, nch, (const u64*)(smem_d + 128), smem_d);
+    out[i] = exact ? order_key(x[i], P.m, P.m_mask, smem_d) : order_key_fast(x[i], P.m, P.m_mask, cfg, (const u64*)(smem_d + 128), smem_d);
 }
 
 // value of a wave-uniform lane, through SGPRs
@@ -695,9 +743,9 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     constexpr bool CLS = MM < 12;  // minimizer_idx classes in the routing id exist only where 2m < 24 (brisk_hip_create)
     extern __shared__ double smem_d[];
     const double* s_coef = smem_d;                        // 128
-    const u64* s_tabs = (const u64*)(smem_d + 128);       // nch*256 packed fixed-point chunk sums
+    const u64* s_tabs = (const u64*)(smem_d + 128);       // the packed fixed-point chunk tables
     const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const u32 n_tab = 128 + (NCH ? (u32)NCH : cfg.nch) * 256;
+    const u32 n_tab = MM ? 128 + cls_base(MM ? MM : 1, cls_nch(MM ? MM : 1)) : cfg.n_tab;
     for (u32 i = tid; i < n_tab; i += blockDim.x) smem_d[i] = g_tabs[i];
     unsigned long long* s_wbase = (unsigned long long*)(smem_d + n_tab);      // block's slot base at the final flush
     u32* s_wcnt = (u32*)(s_wbase + 1);                                         // [16] records left per wave
@@ -705,7 +753,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     u64* s_q0 = q_ent + cfg.qcap;                  // [64] stream index of every lane's first nt
     u32* s_tag = (u32*)(s_q0 + 64);                // [64] every lane's tag (read index, or chunk slot)
 
-    const u32 k = KK ? (u32)KK : P.k, m = MM ? (u32)MM : P.m, w = k - m, nch = NCH ? (u32)NCH : cfg.nch;
+    const u32 k = KK ? (u32)KK : P.k, m = MM ? (u32)MM : P.m, w = k - m;
     const u64 M = MM ? ((1ull << (2 * MM)) - 1) : P.m_mask;
     const u32 ksh = 2 * m > 30 ? 2 * m - 30 : 0;  // the mix's bits below its top 30
     const u32 nlow = k < 32 ? k : 32, nlow1 = k - 1 < 32 ? k - 1 : 32;  // nts of a k-mer / (k-1)-mer that get_minimizer sees (F2)
@@ -744,7 +792,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         scan_final_flush<CLS>(P, packed, out, q_ent, s_q0, s_tag, 0, s_wcnt, s_wbase);
         return;
     }
-    const u64 KEY0 = order_key_fast<NCH>(0, m, M, nch, s_tabs, s_coef);
+    const u64 KEY0 = order_key_fast<NCH, MM>(0, m, M, cfg, s_tabs, s_coef);
     const u64 KEY0s = read_lane_u64(KEY0, 0);  // the same value, in scalar registers
 
     // ---- prologue: the low 64 bits of the (k-1)-mer; its last m-mer seeds the rolling candidates
@@ -768,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
                 const u64 fwd = (low64 >> (2 * i)) & M;
                 const u64 rcv = rc64(fwd, m);
                 rv = rcv < fwd;
-                key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+                key = order_key_fast<NCH, MM>(rv ? rcv : fwd, m, M, cfg, s_tabs, s_coef);
             } else {  // beyond the low 64 bits: the all-A m-mer
                 key = KEY0;
                 rv = false;
@@ -827,7 +875,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         low64 = (low64 << 2) | c;
         const u64 cf = low64 & M;
         const bool revf = cr < cf;
-        const u64 h = order_key_fast<NCH>(revf ? cr : cf, m, M, nch, s_tabs, s_coef);
+        const u64 h = order_key_fast<NCH, MM>(revf ? cr : cf, m, M, cfg, s_tabs, s_coef);
         mini_pos += act ? 1u : 0u;
         const bool expired = act && mini_pos > w;                  // Kmers.cpp:551
         const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
@@ -871,7 +919,7 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             const u64 fwd = (lowL >> (2 * wl)) & M;
             const u64 rcv = rc64(fwd, m);
             const bool rv = rcv < fwd;
-            u64 key = order_key_fast<NCH>(rv ? rcv : fwd, m, M, nch, s_tabs, s_coef);
+            u64 key = order_key_fast<NCH, MM>(rv ? rcv : fwd, m, M, cfg, s_tabs, s_coef);
             // an order-preserving 32-bit prefix of the key (class, then the top 30 bits of the mix): the half's minimum goes
             // over the DPP network on it; two windows agreeing on all 32 bits are told apart by the 64-bit path below
             u32 k32 = ((u32)(key >> 62) << 30) | (u32)((key & M) >> ksh);
