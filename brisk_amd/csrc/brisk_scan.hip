@@ -196,9 +196,12 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
     const u64 mm = w4_shr(S, 2 * idx_end).w0 & P.m_mask;
     const u64 h = mix2m(mm, P.m_mask);
     const u32 rbase = routing_base(P, h);  // Brisk.hpp:135-137, plus the extra routing bits of the hash
-    // replace the minimizer by its hash (replace_slice, Kmers.cpp:149-159)
-    const W4 hole = w4_shl(W4{P.m_mask, 0, 0, 0}, 2 * idx_end);
-    S = w4_or(w4_andn(S, hole), w4_shl(W4{h, 0, 0, 0}, 2 * idx_end));
+    // replace the minimizer by its hash (replace_slice, Kmers.cpp:149-159): both have 2m bits, so XOR-ing their difference
+    // into place does it with one shift
+    {
+        const W4 d = w4_shl(W4{mm ^ h, 0, 0, 0}, 2 * idx_end);
+        S = W4{S.w0 ^ d.w0, S.w1 ^ d.w1, S.w2 ^ d.w2, S.w3 ^ d.w3};
+    }
     // drop the b bucket nts at suffix offset idx_end + suff_reduc (get_compacted, Kmers.cpp:138-145)
     const u32 cut = idx_end + P.suff_reduc;
     const W4 lowm = w4_mask(2 * cut);
@@ -405,6 +408,9 @@ struct ScanCfg {
 // NCH > 0: compile-time chunk count (unrolled look-ups); MM > 0: compile-time m, the whole layout folds into the instructions
 template <int NCH, int MM>
 __device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg, const u64* tabs, const double* coef) {
+#ifdef SCAN_ATTR_NOCLASS  // attribution builds (tools/scan_attribution.py): wrong results, timing only
+    return (u32)x & 1u;
+#endif
     u64 acc;
     if (MM > 0) {
         constexpr u32 mm = MM > 0 ? (u32)MM : 1u;
@@ -433,6 +439,9 @@ __device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg,
 }
 template <int NCH = 0, int MM = 0>
 __device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, const ScanCfg& cfg, const u64* tabs, const double* coef) {
+#ifdef SCAN_ATTR_NOMIX
+    return ((u64)decy_class_fast<NCH, MM>(x, m, cfg, tabs, coef) << 62) + (x ^ (x >> 7));
+#endif
     return ((u64)decy_class_fast<NCH, MM>(x, m, cfg, tabs, coef) << 62) + mix2m(x, M);
 }
 
@@ -705,6 +714,11 @@ __device__ __forceinline__ void scan_final_flush(const BriskParams& P, const u32
                                                  const u32* s_tag, u32 qcount, u32* s_wcnt, unsigned long long* s_wbase) {
     const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const u32 n_mine = queue_records<CLS>(P, q_ent, qcount);
+    if (out.bins) {  // binned records need no slots: no reservation, no barrier
+        if (lane == 0 && n_mine) atomicAdd(out.n_rec, (unsigned long long)n_mine);
+        emit_queue<CLS>(P, packed, out, q_ent, s_q0, s_tag, qcount, 0);
+        return;
+    }
     if (lane == 0) s_wcnt[wid] = n_mine;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -753,6 +767,14 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     u64* s_q0 = q_ent + cfg.qcap;                  // [64] stream index of every lane's first nt
     u32* s_tag = (u32*)(s_q0 + 64);                // [64] every lane's tag (read index, or chunk slot)
 
+    if (KK) {  // the record builder reads these from P: let them fold there too
+        P.k = KK;
+        P.w = KK - MM;
+    }
+    if (MM) {
+        P.m = MM;
+        P.m_mask = (1ull << (2 * MM)) - 1;
+    }
     const u32 k = KK ? (u32)KK : P.k, m = MM ? (u32)MM : P.m, w = k - m;
     const u64 M = MM ? ((1ull << (2 * MM)) - 1) : P.m_mask;
     const u32 ksh = 2 * m > 30 ? 2 * m - 30 : 0;  // the mix's bits below its top 30
@@ -904,6 +926,13 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         // sticks out of the low 64 bits (F2); windows 32.. of a k > 32 are the all-A m-mer (KEY0), folded in
         // below without lanes.
         unsigned long long need = __ballot(expired && !dead);
+#ifdef SCAN_ATTR_NORESCAN
+        if (expired) {
+            mini_pos = 0;
+            mini_hash = h;
+        }
+        need = 0;
+#endif
         while (need) {
             const int LA = __ffsll((long long)need) - 1;
             need &= need - 1;
@@ -986,11 +1015,17 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         // turn queued super-k-mers into records with full waves.  All waves append to one record counter, and
         // same-address atomics serialise device-wide (~15 ns each): one reservation per flush, not per record
         if (qcount + 64 > cfg.qcap) {
+#ifndef SCAN_ATTR_NOEMIT
             const u32 n_out = queue_records<CLS>(P, q_ent, qcount);
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)n_out);
-            base = read_lane_u64(base, 0);
+            if (out.bins) {  // binned records take their slots from the partitions' counters: the record counter is a total, nobody waits for it
+                if (lane == 0) atomicAdd(out.n_rec, (unsigned long long)n_out);
+            } else {
+                if (lane == 0) base = atomicAdd(out.n_rec, (unsigned long long)n_out);
+                base = read_lane_u64(base, 0);
+            }
             emit_queue<CLS>(P, packed, out, q_ent, s_q0, s_tag, qcount, base);
+#endif
             qcount = 0;
         }
     }
@@ -1008,5 +1043,8 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         }
         qcount += (u32)__popcll(bal);
     }
+#ifdef SCAN_ATTR_NOEMIT
+    qcount = 0;
+#endif
     scan_final_flush<CLS>(P, packed, out, q_ent, s_q0, s_tag, qcount, s_wcnt, s_wbase);
 }
