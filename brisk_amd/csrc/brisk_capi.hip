@@ -2236,6 +2236,14 @@ BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mme
 }
 
 #ifdef BRISK_PHASE_PROF
+BRISK_API int brisk_hip_debug_scan_counts(uint64_t out[8], int reset) {  // debug builds only (tools/phase_profile.py)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_cnt), 8 * 8) != hipSuccess) return BRISK_HIP_EHIP;
+    if (reset) {
+        uint64_t z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_cnt), z, 8 * 8) != hipSuccess) return BRISK_HIP_EHIP;
+    }
+    return BRISK_HIP_OK;
+}
 BRISK_API int brisk_hip_debug_phases(uint64_t out[32], int reset) {  // debug builds only (tools/phase_profile.py)
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * 8) != hipSuccess) return BRISK_HIP_EHIP;
     if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_cnt), 16 * 8) != hipSuccess) return BRISK_HIP_EHIP;

@@ -495,17 +495,26 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
         for (u32 t = t0; t < t_end; t++) {
             const u32 tn = t + 1;
             PartDesc dn{};
-            RecRegs rn{0, 0, 0, 0, 0};  // first records of the next partition
-            if (tn < t_end) {
-                dn = batch_desc(mine, tn - t0);
-                rn = load_part_recs(P, src, dn.part, dn.r_begin, dn.r_begin, min(dn.n_rec, (u32)WI_MAX_REC), lane);
-            }
+            if (tn < t_end) dn = batch_desc(mine, tn - t0);
+            // The next partition's records are requested when this partition is done, into rr.  Round 2 requested them at the top
+            // of the current partition, into a second set of registers: the memory counter retires loads in issue order and the
+            // compiler's wait in front of the first use of rr is vmcnt(0), so every partition began by sitting out the round trip
+            // of the prefetch it had just issued, and kept eight more registers live for it (31.1 ms per 50 M reads against 30.0
+            // this way; requesting them in front of the partition's last stores, or where the last chunk has expanded its
+            // records, measured 32.6 / 32.3: DESIGN.md section 4).
+#define NEXT_PARTITION                                                                                                  \
+    {                                                                                                                   \
+        d = dn;                                                                                                         \
+        if (tn < t_end) rr = load_part_recs(P, src, d.part, d.r_begin, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane); \
+    }
 
-            if (ix.huge_at && d.n_inst > ix.huge_at) {  // a block of 16 waves takes this one (k_insert_huge)
-                d = dn;
-                rr = rn;
-                continue;
-            }
+            // rr must have landed on EVERY path before it is requested again at the end of the partition (a load's destination
+            // is not written while the load is in flight), a partition left to k_insert_huge or one whose lanes all skip the
+            // store below included: without this unconditional use the compiler waits at the end of every partition instead --
+            // for all the stores the partition has just issued.
+            asm volatile("" ::"v"(rr.w0), "v"(rr.w1), "v"(rr.w2), "v"(rr.w3), "v"(rr.w4));
+            do {  // (one pass: a partition that is not this kernel's leaves through `break`)
+            if (ix.huge_at && d.n_inst > ix.huge_at) break;  // a block of 16 waves takes this one (k_insert_huge)
             CNT(0, 1)
             const u32 part = d.part;
             u32 r_end = d.r_begin + d.n_rec;
@@ -743,6 +752,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                 // trip as well.  They were requested a partition's worth of work ago.
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #endif
+
                 PHASE(6)
                 CNT(6, (n_new + 63) / 64)
                 CNT(7, n_new)
@@ -840,8 +850,9 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                     }
                 }
             }
-            d = dn;
-            rr = rn;
+            } while (0);
+            NEXT_PARTITION
+#undef NEXT_PARTITION
             PHASE(9)
         }
     }

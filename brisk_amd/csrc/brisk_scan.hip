@@ -747,6 +747,13 @@ __device__ __forceinline__ u32 row_min_u32(u32 x) {
     return x;
 }
 
+#ifdef BRISK_PHASE_PROF  // debug builds only (tools/phase_profile.py): event counts of k_scan2
+__device__ unsigned long long g_scan_cnt[8];  // [0] wave-steps [1] expiries [2] re-scan rounds [3] of them with two k-mers [4] super-k-mers queued [5] flush passes
+#define SCNT(i, v) scan_cnt[i] += (v);
+#else
+#define SCNT(i, v)
+#endif
+
 // MODE 0: reads, insert; 1: reads, query (stops a read at a returned minimizer of 0); 2: virtual reads (chunks of long sequences)
 // KK, MM: k and m as compile-time constants for the common parameter sets (0: from P) -- folds the shifts and masks and,
 // above all, frees scalar registers: the generic kernel spills 70+ of them into vector lanes and pays a v_readlane per use
@@ -880,7 +887,11 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
     u64 buf = 0;
     const u32 Km = k - m;
     const u32 lane_bits = lane << 18;
+#ifdef BRISK_PHASE_PROF
+    unsigned long long scan_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (u32 p = 0; p < max_nk; p++) {
+        SCNT(0, 1)
         const bool act = p < nk && !dead;
         if (VR && live) {  // the enumerator state before step p, for the chunk-seam check
             if (p == emit_from && !seq_first && !seeded) cc.spec[vslot] = ChunkState{mini_hash, mini_pos | ((reversed ? 1u : 0u) << 31), 1u};
@@ -920,12 +931,14 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
                 if (query_mode) n_emitted++;
             }
             qcount += (u32)__popcll(bal);
+            SCNT(4, (u32)__popcll(bal))
         }
         // re-scans (get_minimizer on the low 64 bits, Kmers.cpp:367-408): two lanes' k-mers per round, one
         // window per lane of a half-wave.  Window i of a k-mer is (low64 >> 2i) & M -- zero-padded where it
         // sticks out of the low 64 bits (F2); windows 32.. of a k > 32 are the all-A m-mer (KEY0), folded in
         // below without lanes.
         unsigned long long need = __ballot(expired && !dead);
+        SCNT(1, (u32)__popcll(need))
 #ifdef SCAN_ATTR_NORESCAN
         if (expired) {
             mini_pos = 0;
@@ -937,6 +950,8 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
             const int LA = __ffsll((long long)need) - 1;
             need &= need - 1;
             const bool two = need != 0;
+            SCNT(2, 1)
+            SCNT(3, two ? 1 : 0)
             int LB = LA;
             if (two) {
                 LB = __ffsll((long long)need) - 1;
@@ -1043,6 +1058,10 @@ __global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, cons
         }
         qcount += (u32)__popcll(bal);
     }
+#ifdef BRISK_PHASE_PROF
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_scan_cnt[i], scan_cnt[i]);
+#endif
 #ifdef SCAN_ATTR_NOEMIT
     qcount = 0;
 #endif

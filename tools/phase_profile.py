@@ -28,9 +28,12 @@ ix = brisk_amd.BriskHip(k, m, b)
 ix.synth_reads(G, 0, reads, 150, d_packed.data_ptr(), d_starts.data_ptr())
 ix.sync()
 buf = (C.c_uint64 * 32)()
+sbuf = (C.c_uint64 * 8)()
+L.brisk_hip_debug_scan_counts.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 for rep in range(2):
     ix.clear()
     L.brisk_hip_debug_phases(buf, 1)
+    L.brisk_hip_debug_scan_counts(sbuf, 1)
     ix.profile_reset(); ix.profile_enable(True)
     ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), reads)
     ix.sync()
@@ -45,4 +48,8 @@ for i, n in enumerate(names):
 cn = ["partitions", "chunks", "record-dedupe attempts", "expand its (x64 lanes)", "instances", "records", "append passes", "new entries", "CAS rounds x its"]
 for i, n in enumerate(cn):
     print(f"{n:28s} {buf[16 + i]:14d}  per partition {buf[16 + i] / max(buf[16], 1):8.3f}")
+L.brisk_hip_debug_scan_counts(sbuf, 0)
+sn = ["wave-steps", "expiries (lanes)", "re-scan rounds", "  of them with two k-mers", "super-k-mers queued"]
+for i, n in enumerate(sn):
+    print(f"k_scan2 {n:28s} {sbuf[i]:14d}  per wave-step {sbuf[i] / max(sbuf[0], 1):8.3f}  per read {sbuf[i] / reads:8.3f}")
 print(ix.stats())
