@@ -866,7 +866,10 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
 
 
 #ifndef WI_WAVES_PER_EU_FAST
-#define WI_WAVES_PER_EU_FAST 4   // 5 (<= 96 registers) spills 18 of them: 35.0 ms at 4096 waves, 30.3 at 5120 -- no better than 4 waves without scratch (30.4)
+// Five waves per SIMD (<= 96 registers, 20 waves per CU: what the LDS holds at 7.7 KB a wave).  The body needs 115 since the
+// next partition's records share the current ones' registers (127 before: 18 spilled at 96 and five waves gained nothing);
+// at 96 it spills 10 to scratch and the fifth wave is worth it: 29.8 -> 26.3 ms per 50 M reads (5120 resident waves).
+#define WI_WAVES_PER_EU_FAST 5
 #endif
 template <u32 NW, u32 KB, u32 SHIFT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WI_WAVES_PER_EU_FAST, 8))) k_insert_fast(BriskParams P, RecSrc src, const PartDesc* __restrict__ desc,

@@ -536,7 +536,10 @@ def test_order_keys_fast_and_exact_paths(B, O):
     fold both equal the reference's keys, on random and on low-complexity m-mers (where
     R(x) is mathematically 0 and only rounding noise decides nothing)."""
     rng = random.Random(77)
-    for k, m, b in ((63, 21, 14), (31, 11, 4), (63, 31, 12), (21, 7, 3), (31, 15, 14)):
+    # every shape of the chunk tables (brisk_scan.hip, cls_nch / cls_width): 1 chunk (m 5), [5,4], [6,5], [5,4,4], [5,5,5], [5,4,4,4] (a
+    # chunk across the 32-bit boundary), [5,5,5,4], [6,5,5,5], 5 chunks (23, 25), 6 (27, 29), 7 (31)
+    for k, m, b in ((63, 21, 14), (31, 11, 4), (63, 31, 12), (21, 7, 3), (31, 15, 14), (21, 5, 2), (31, 9, 4), (41, 13, 6), (47, 17, 8), (55, 19, 9),
+                    (63, 23, 11), (63, 25, 12), (63, 27, 13), (63, 29, 14), (9, 3, 1)):
         M = (1 << (2 * m)) - 1
         xs = [rng.getrandbits(2 * m) for _ in range(200000)]
         for unit in ("A", "C", "G", "T", "AC", "AG", "AT", "CG", "CT", "GT", "ACG", "ACT", "AAC", "ACGT", "AACC", "ACCGT"):
@@ -786,7 +789,7 @@ def test_batch_splits_when_the_arena_reserve_does_not_fit(B, O, monkeypatch):
     want = O.count(reads, k, m, b)
     inst = sum(len(r) - k + 1 for r in reads)
     monkeypatch.delenv("BRISK_NO_VMM", raising=False)  # this test sets it itself, further down
-    slack = 4096 * 16384  # INSERT_SLOTS x ARENA_CHUNK of csrc/brisk_insert.hip: one partly used private chunk per persistent wave
+    slack = 5120 * 16384  # resident insert waves (20 per CU x 256 CUs) x ARENA_CHUNK of csrc/brisk_insert.hip: one partly used private chunk per persistent wave
     monkeypatch.setenv("BRISK_ARENA_LIMIT", str(slack + inst // 2))  # the slack plus half the pessimistic bound
     assert gpu_count(B, reads, k, m, b) == want
     monkeypatch.setenv("BRISK_ARENA_LIMIT", "1000")  # nothing fits: a clean error, not a crash
