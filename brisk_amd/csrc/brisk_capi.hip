@@ -608,7 +608,7 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
         const u32 bt = h->scan_waves * 64;
         const dim3 grid(nblocks(n_items, bt)), block(bt);
         // instantiations: {k and m compile-time for the common parameter sets (the class tables' layout folds into the
-        // instructions), or from P with the chunk count unrolled (4: m 17..21, 3: m 12..16, 2: m 7..11; else a loop)} x mode
+        // instructions), or from P with the chunk count unrolled (6: m 27..29, 4: m 17..19, 3: m 11..15 at CLS_W 5; else a loop)} x mode
 #define LAUNCH_SCAN2(NCH, MODE, KK, MM) \
     hipLaunchKernelGGL((k_scan2<NCH, MODE, KK, MM>), grid, block, h->scan_lds, h->stream, h->P, h->scfg, d_packed, d_starts, n_items, h->d_tabs, out, cc)
 #define LAUNCH_SCAN2_MODES(NCH, KK, MM)                    \
@@ -621,9 +621,9 @@ int launch_scan(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
         if (k == 63 && m == 21) LAUNCH_SCAN2_MODES(0, 63, 21)
         else if (k == 31 && m == 15) LAUNCH_SCAN2_MODES(0, 31, 15)  // the reference's default parameters (apps/counter.cpp:355)
         else if (k == 31 && m == 11) LAUNCH_SCAN2_MODES(0, 31, 11)
+        else if (h->scfg.nch == 6) LAUNCH_SCAN2_MODES(6, 0, 0)
         else if (h->scfg.nch == 4) LAUNCH_SCAN2_MODES(4, 0, 0)
         else if (h->scfg.nch == 3) LAUNCH_SCAN2_MODES(3, 0, 0)
-        else if (h->scfg.nch == 2) LAUNCH_SCAN2_MODES(2, 0, 0)
         else LAUNCH_SCAN2_MODES(0, 0, 0)
 #undef LAUNCH_SCAN2_MODES
 #undef LAUNCH_SCAN2
@@ -1404,13 +1404,17 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             // LDS: the class tables once per block, an emit queue per wave.  Eight waves per block, two blocks per CU.
             const size_t fixed = (size_t)(n_tab + 9) * 8;
             const size_t lds_max = 160 * 1024;
-            // big tables (m = 21: 57 KB): shorter queues rather than one block per CU (measured at m = 21, per 50 M reads:
-            // qcap 224 31.2 ms, 256 31.8, 192 32.4; one 16-wave block with qcap 320 43.9)
-            while (c.qcap > 224 && 2 * (fixed + 8 * (size_t)(c.qcap + 96) * 8) > lds_max - 4096) c.qcap -= 32;
+            // as many 8-wave blocks per CU as the kernel's registers allow (SCAN_WAVES_PER_EU waves per SIMD), the queues
+            // shortened if that is what it takes (not below 224 entries); if the tables are too big for that, fewer blocks
+            const bool spec = (k == 63 && m == 21) || (k == 31 && m == 15) || (k == 31 && m == 11);  // launch_scan's instantiations with k and m as constants
+            u32 blocks_per_cu = std::max<u32>(1, (u32)(scan_waves_per_eu(spec ? (int)k : 0, spec ? (int)m : 0) * 4) / 8);
+            auto lds_of = [&](u32 q, u32 waves) { return fixed + waves * (size_t)(q + 96) * 8; };  // queue + the lanes' read starts and tags
+            while (blocks_per_cu > 1 && blocks_per_cu * lds_of(224, 8) > lds_max - 2048) blocks_per_cu--;
+            while (c.qcap > 224 && blocks_per_cu * lds_of(c.qcap, 8) > lds_max - 2048) c.qcap -= 32;
             if (const char* e = getenv("BRISK_SCAN_QCAP")) c.qcap = (u32)std::max(128, atoi(e));
-            const size_t per_wave = (size_t)(c.qcap + 96) * 8;  // queue + the lanes' read starts and tags
-            u32 wv = 8;  // 2 blocks per CU, 4 waves per SIMD; block sizes that are not a multiple of 4 waves place badly
-            if (2 * (fixed + wv * per_wave) > lds_max) wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);  // big m: one block per CU
+            const size_t per_wave = (size_t)(c.qcap + 96) * 8;
+            u32 wv = 8;  // 4 waves per SIMD and block; block sizes that are not a multiple of 4 waves place badly (10-wave blocks: 49 ms against 31)
+            if (lds_of(c.qcap, 8) > lds_max) wv = (u32)std::min<size_t>(16, (lds_max - fixed) / per_wave);
             if (const char* e = getenv("BRISK_SCAN_WAVES")) wv = (u32)std::min(16, std::max(1, atoi(e)));
             h->scan_waves = wv;
             h->scan_lds = fixed + wv * per_wave;
@@ -1419,7 +1423,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
             if (h->scan_lds > lds_attr) {
                 lds_attr = h->scan_lds;
 #define SCAN2_FNS(NCH, KK, MM) (const void*)k_scan2<NCH, 0, KK, MM>, (const void*)k_scan2<NCH, 1, KK, MM>, (const void*)k_scan2<NCH, 2, KK, MM>
-                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(2, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(0, 31, 11), SCAN2_FNS(0, 31, 15), SCAN2_FNS(0, 63, 21),
+                const void* fns[] = {SCAN2_FNS(0, 0, 0), SCAN2_FNS(3, 0, 0), SCAN2_FNS(4, 0, 0), SCAN2_FNS(6, 0, 0), SCAN2_FNS(0, 31, 11), SCAN2_FNS(0, 31, 15), SCAN2_FNS(0, 63, 21),
                                      (const void*)k_debug_keys};
 #undef SCAN2_FNS
                 for (const void* fn : fns) HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));

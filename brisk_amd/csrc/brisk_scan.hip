@@ -354,26 +354,20 @@ __device__ __forceinline__ unsigned long long lanes_below(u32 lane) { return (1u
 //     the minimum key);
 //   * closed super-k-mers are queued in LDS and turned into records by full waves.
 // ---- layout of the decycling chunk tables (shared by the host builder in brisk_capi.hip and the kernels) ----------------
-// An m-mer is cut into L = ceil((m-1)/5) chunks of 5 nts (one of 6 where m = 5L+1; fewer nts where m is small), low nts
-// first: m = 21 -> [6,5,5,5], 15 -> [5,5,5], 11 -> [6,5].  A look-up costs the same issue slots whatever its table's size
-// (tools/valu_rates.hip: a random ds_read_b64 with its address arithmetic ~26 cycles per wave against ~4.3 for a vector
-// instruction), so fewer, larger tables are cheaper: 4 look-ups instead of 6 at m = 21 -- for 57 KB of LDS instead of
-// 12, which is as far as it goes: two 8-wave blocks per CU must still fit with their emit queues (ONE 16-wave block per CU
-// ran the scan at 43.9 ms against 31.2: a block waits for its slowest wave with nothing else resident).  So the 6-nt chunk
-// is used up to L = 4 only (m = 31 -> [5,5,5,4,4,4,4]).  (-DBRISK_CLS_W4: 4-nt chunks, for A/B.)
-__host__ __device__ constexpr u32 cls_nch(u32 m) {
-#ifdef BRISK_CLS_W4
-    return (m + 3) / 4;
-#else
-    return m <= 6 ? 1u : (m + 3) / 5 + (m > 21 && m % 5 == 1 ? 1u : 0u);
+// An m-mer is cut into L = ceil(m / CLS_W) chunks of at most CLS_W nts, as even as they come, low nts first: CLS_W = 5 gives
+// m = 21 -> [5,4,4,4,4], 15 -> [5,5,5], 11 -> [4,4,3], 31 -> [5,5,5,4,4,4,4].  One look-up per chunk (tools/valu_rates.hip:
+// a random ds_read_b64 with its address arithmetic costs ~26 cycles per wave against ~4.3 for a vector instruction), so wider
+// chunks mean fewer look-ups -- CLS_W = 6: m = 21 -> [6,5,5,5], four instead of five -- but also tables of 57 KB instead of
+// 16, and the LDS decides how many waves stay resident.  Measured at m = 21, ms per 50 M reads: CLS_W 6, two 8-wave blocks per
+// CU (4 waves per SIMD, all that fits): 30.3; CLS_W 4 / 5, three blocks (6 waves per SIMD, 80 registers, no scratch):
+// 26.1 / 25.6; four blocks (64 registers, 16 of them spilled): 33.9; one 16-wave block per CU 43.9, 10-wave blocks 49
+// (profiles/r02_scan_attribution.txt).  Occupancy is worth more than a look-up, scratch costs more than occupancy.
+#ifndef CLS_W
+#define CLS_W 5
 #endif
-}
+__host__ __device__ constexpr u32 cls_nch(u32 m) { return (m + CLS_W - 1) / CLS_W; }
 __host__ __device__ constexpr u32 cls_width(u32 m, u32 c) {  // nts in chunk c
-#ifdef BRISK_CLS_W4
-    return m - 4 * c < 4 ? m - 4 * c : 4u;
-#else
     return m / cls_nch(m) + (c < m % cls_nch(m) ? 1u : 0u);
-#endif
 }
 __host__ __device__ constexpr u32 cls_off(u32 m, u32 c) {  // first nt of chunk c
     u32 o = 0;
@@ -757,8 +751,15 @@ __device__ unsigned long long g_scan_cnt[8];  // [0] wave-steps [1] expiries [2]
 // MODE 0: reads, insert; 1: reads, query (stops a read at a returned minimizer of 0); 2: virtual reads (chunks of long sequences)
 // KK, MM: k and m as compile-time constants for the common parameter sets (0: from P) -- folds the shifts and masks and,
 // above all, frees scalar registers: the generic kernel spills 70+ of them into vector lanes and pays a v_readlane per use
+// Waves per SIMD the kernel is compiled for: six (three 8-wave blocks per CU, 80 registers) where k and m are compile-time
+// constants and there are no minimizer_idx classes -- those bodies fit 80 registers without scratch (or nearly: two of them
+// at k31 m15) --, four for the others, which would spill 23-27.
+#ifndef SCAN_WAVES_PER_EU
+#define SCAN_WAVES_PER_EU 6
+#endif
+__host__ __device__ constexpr int scan_waves_per_eu(int KK, int MM) { return KK && MM >= 12 ? SCAN_WAVES_PER_EU : 4; }
 template <int NCH, int MODE, int KK, int MM>
-__global__ void __launch_bounds__(1024) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_waves_per_eu(KK, MM), 8))) k_scan2(BriskParams P, ScanCfg cfg, const u32* __restrict__ packed, const u64* __restrict__ starts,
                                                 u64 n_reads, const double* __restrict__ g_tabs, ScanOut out, ChunkCtl cc) {
     constexpr bool VR = MODE == 2, query_mode = MODE == 1;
     constexpr bool CLS = MM < 12;  // minimizer_idx classes in the routing id exist only where 2m < 24 (brisk_hip_create)
