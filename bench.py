@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--coverage", type=float, default=15.0)
     ap.add_argument("--part-bits", type=int, default=0, help="log2(#partitions); 0: library default")
-    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000, help="reads of the CPU baseline sample (about 15 s of the reference on the box's host cores)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000, help="reads of the CPU baseline sample (10-15 s of the reference on the box's CPU share; the leg stops after ~30 s whatever the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--get", action="store_true", help="also time the get path afterwards (N=1): per-read sums of counts over the same reads; reported under \"get\"")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
@@ -285,12 +285,18 @@ def cpu_baseline(k, m, b, L, coverage, sample_reads):
     reads = O.synth_reads(G, 0, sample_reads, L)
     flat = np.ascontiguousarray(reads.reshape(-1))
     offs = (np.arange(sample_reads + 1, dtype=np.uint64) * np.uint64(L))
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cpu_share()
+    # the sample goes in slices into one index, and stops early on a host that turns out slow: the leg is bounded in time
+    # (~30 s), not only in reads
+    slice_reads, budget_s, done = 500_000, 30.0, 0
     if oracle.have_ref():
         R = oracle.Ref()
         h = R.index_new(k, m, b)
         t0 = time.perf_counter()
-        R.index_insert_reads(h, flat, offs, threads=cores)
+        while done < sample_reads and (done == 0 or time.perf_counter() - t0 < budget_s):
+            n = min(slice_reads, sample_reads - done)
+            R.index_insert_reads(h, flat[done * L:(done + n) * L], offs[:n + 1], threads=cores)
+            done += n
         dt = time.perf_counter() - t0
         nk, _ = R.index_stats(h)
         R.index_free(h)
@@ -298,13 +304,45 @@ def cpu_baseline(k, m, b, L, coverage, sample_reads):
     else:
         h = O.index_new(k, m, b)
         t0 = time.perf_counter()
-        O.index_insert_reads(h, flat, offs)
+        while done < sample_reads and (done == 0 or time.perf_counter() - t0 < budget_s):
+            n = min(slice_reads, sample_reads - done)
+            O.index_insert_reads(h, flat[done * L:(done + n) * L], offs[:n + 1])
+            done += n
         dt = time.perf_counter() - t0
         nk, _ = O.index_stats(h)
         O.index_free(h)
         kind, used = "port", 1
     return {"value": round(nk / dt, 1), "unit": "k-mers/s", "cores": used, "kind": kind,
-            "sample": "%d synthetic %d bp reads, %gx coverage (genome %d bp): %d entries in %.2f s" % (sample_reads, L, coverage, G, nk, dt)}
+            "sample": "%d of %d synthetic %d bp reads, %gx coverage (genome %d bp): %d entries in %.2f s" % (done, sample_reads, L, coverage, G, nk, dt)}
+
+
+def host_cpu_share():
+    """Threads for the CPU baseline: the cores this process may actually use.  The affinity mask of a GPU box lists every
+    core of the host (256) while its cgroup grants a share of them (16 for one GPU): the reference's OpenMP path with
+    its lock stripes collapses when it is given more threads than cores (measured on one box, 1 M reads: 16 threads 15.5 M
+    entries/s, 32 threads 1.65 M, 256 threads 0.51 M), so the strongest -- the honest -- baseline runs with the share.
+    BRISK_CPU_THREADS overrides."""
+    if os.environ.get("BRISK_CPU_THREADS"):
+        return max(1, int(os.environ["BRISK_CPU_THREADS"]))
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:  # noqa: BLE001
+        pass
+    if quota is None:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // per)
+        except Exception:  # noqa: BLE001
+            pass
+    if quota is None:
+        quota = 16 if aff > 32 else aff  # no quota visible: a GPU box's share for one GPU
+    return max(1, min(aff, quota))
 
 
 if __name__ == "__main__":
