@@ -10,7 +10,10 @@ src, dst, reads, k, m, b = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.a
 kern = collections.defaultdict(lambda: {"launches": 0})
 for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     seen = collections.Counter()
-    for f in glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True):
+    # gpurun merges every call's gpurun_out/ into the local one: an earlier collection's files lie beside the latest.  Only the
+    # newest pass counts (a sum over two generations would be an average of two different kernels).
+    files = sorted(glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != ctr:
                 continue
@@ -33,7 +36,7 @@ out = {
     "kernels": {n: v for n, v in sorted(kern.items()) if n.startswith("k_")},
 }
 json.dump(out, open(dst + "_pmc_traffic.json", "w"), indent=1)
-for f in glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True):
+for f in sorted(glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1:]:
     shutil.copy(f, dst + "_kernel_stats.csv")
 if os.path.exists(os.path.join(src, "bench_under_trace.json")):
     shutil.copy(os.path.join(src, "bench_under_trace.json"), dst + "_bench_under_trace.json")
