@@ -1,5 +1,9 @@
+"""The reference's CPU path (oracle/_ref) by thread count on this host: 1 M synthetic 150 bp reads, k63 m21 b14.  On a GPU box the
+affinity mask lists every core of the host while the cgroup grants a share of them; past that share the OpenMP path with its lock
+stripes collapses (profiles/r02_cpu_threads.txt).  bench.py's cpu_baseline takes its thread count from the cgroup quota for that reason.
+    python3 tools/cpu_threads_probe.py"""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, oracle
 O = oracle.Oracle(); R = oracle.Ref()
 k, m, b, L = 63, 21, 14, 150
