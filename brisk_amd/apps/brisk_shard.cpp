@@ -5,7 +5,10 @@
 // export_hist -> [exchange] -> insert_records_hist.  The reference is single-process: nothing here has a counterpart in it.
 //
 //   brisk_shard RANK WORLD DIR TRANSPORT TOTAL_READS k m b [coverage]
-//     DIR        a directory all ranks see (rank 0 leaves the ncclUniqueId there; the "files" transport exchanges through it)
+//     DIR        a directory all ranks see (rank 0 leaves the ncclUniqueId there; the "files" transport exchanges through it).
+//                Every file carries the run's token (environment BRISK_SHARD_RUN, the same for all ranks of a run; "" if unset)
+//                and is removed by its last reader, so a second run in the same directory never meets the first one's id or
+//                payloads -- also not those a crashed run left behind, as long as launchers give every run its own token
 //     TRANSPORT  rccl : device = RANK, ncclSend/ncclRecv between device buffers over xGMI
 //                files: every rank on device 0, buffers staged through DIR -- the rehearsal of the N > 1 flow on a one-GPU
 //                       box, where RCCL refuses two ranks on one device (what "gloo --share-gpu" is to bench.py)
@@ -80,7 +83,7 @@ static void publish(const std::string& p, const void* data, size_t bytes) {  // 
         exit(1);
     }
 }
-static void slurp(const std::string& p, void* data, size_t bytes) {
+static void slurp(const std::string& p, void* data, size_t bytes, bool last_reader = true) {
     wait_for(p);
     FILE* f = fopen(p.c_str(), "rb");
     if (!f || (bytes && fread(data, 1, bytes, f) != bytes)) {
@@ -88,6 +91,7 @@ static void slurp(const std::string& p, void* data, size_t bytes) {
         exit(1);
     }
     fclose(f);
+    if (last_reader) unlink(p.c_str());  // every step file has exactly one reader
 }
 
 // The exchange step: every rank hands `send_counts[d]` items of `words` u64 each to rank d (its send buffer is grouped by
@@ -99,18 +103,23 @@ struct Transport {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     int step = 0;
+    std::string run;  // BRISK_SHARD_RUN: part of every file name
 
+    std::string path(const char* kind, int a, int b) const { return dir + "/" + run + kind + std::to_string(step) + "_" + std::to_string(a) + "_" + std::to_string(b); }
     void init() {
+        if (const char* t = getenv("BRISK_SHARD_RUN")) run = std::string(t) + "_";
         if (!rccl) return;
         ncclUniqueId id;
-        const std::string f = dir + "/nccl_id";
+        const std::string f = dir + "/" + run + "nccl_id";
         if (rank == 0) {
             NCCLOK(ncclGetUniqueId(&id));
             publish(f, &id, sizeof id);
         } else {
-            slurp(f, &id, sizeof id);
+            slurp(f, &id, sizeof id, /*last_reader=*/false);  // world - 1 readers: rank 0 removes it once every rank holds the communicator
         }
         NCCLOK(ncclCommInitRank(&comm, world, id, rank));
+        barrier();
+        if (rank == 0) unlink(f.c_str());
     }
     // counts first: how many items every rank is about to send me
     std::vector<uint64_t> exchange_counts(const std::vector<uint64_t>& send_counts) {
@@ -132,8 +141,8 @@ struct Transport {
             HIPOK(hipFree(d_s));
             HIPOK(hipFree(d_r));
         } else {
-            for (int p = 0; p < world; p++) publish(dir + "/c" + std::to_string(step) + "_" + std::to_string(rank) + "_" + std::to_string(p), &send_counts[p], 8);
-            for (int p = 0; p < world; p++) slurp(dir + "/c" + std::to_string(step) + "_" + std::to_string(p) + "_" + std::to_string(rank), &recv_counts[p], 8);
+            for (int p = 0; p < world; p++) publish(path("c", rank, p), &send_counts[p], 8);
+            for (int p = 0; p < world; p++) slurp(path("c", p, rank), &recv_counts[p], 8);
         }
         return recv_counts;
     }
@@ -157,12 +166,12 @@ struct Transport {
             for (int p = 0; p < world; p++) {
                 buf.resize(send_counts[p] * words);
                 if (!buf.empty()) HIPOK(hipMemcpy(buf.data(), d_send + so * words, buf.size() * 8, hipMemcpyDeviceToHost));
-                publish(dir + "/p" + std::to_string(step) + "_" + std::to_string(rank) + "_" + std::to_string(p), buf.data(), buf.size() * 8);
+                publish(path("p", rank, p), buf.data(), buf.size() * 8);
                 so += send_counts[p];
             }
             for (int p = 0; p < world; p++) {
                 buf.resize(recv_counts[p] * words);
-                slurp(dir + "/p" + std::to_string(step) + "_" + std::to_string(p) + "_" + std::to_string(rank), buf.data(), buf.size() * 8);
+                slurp(path("p", p, rank), buf.data(), buf.size() * 8);
                 if (!buf.empty()) HIPOK(hipMemcpy(d_recv + ro * words, buf.data(), buf.size() * 8, hipMemcpyHostToDevice));
                 ro += recv_counts[p];
             }

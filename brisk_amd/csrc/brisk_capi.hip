@@ -85,6 +85,8 @@ struct brisk_hip_index {
     u64 n_pend = 0;
     bool pend_hist_ok = true;   // d_hist counts exactly the pending records
     bool defer = true;          // brisk_hip_options.immediate_inserts == 0 and BRISK_DEFER != 0
+    bool verify = false;        // BRISK_VERIFY=1 at create: every stage hand-over of the host paths is checked (verify_upload, verify_records)
+    bool trace = false;         // BRISK_TRACE=1 at create: one stderr line per batch saying which host path and which insert kernel took it
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
@@ -438,6 +440,8 @@ int list_touched(brisk_hip_index* h, u32* d_n) {
 // already holds this batch's per-partition histogram (the scan filled it).
 // `bl` (binned layout): the scan wrote the records into per-partition bins (bl->bins, bin_cap records each) and the
 // n_ovf records beyond them into bl->ovf; d_hist holds the histogram.  Null: d_rec holds the records, in any order.
+int verify_records(brisk_hip_index* h, const u64* d_rec, u64 n_rec, u64 want, const char* what);
+int verify_hist(brisk_hip_index* h, u64 want_rec, u64 want_inst, const char* what);
 struct BinLayout {
     u64* bins;
     u32 bin_cap;
@@ -580,6 +584,8 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
 #undef LAUNCH_INSERT_FAST
 #undef LAUNCH_INSERT
         if ((rc = launch_check(h, big ? "k_insert_big" : "k_insert"))) return rc;
+        if (h->trace) fprintf(stderr, "[brisk_hip] path: insert of %llu records (%s layout, histogram %s) into %u partitions: %s, %u partitions to k_insert_huge\n", (unsigned long long)n_rec,
+                              bl ? "binned" : "classic", have_hist ? "from the scan" : "counted here", n_touched, big ? "k_insert_big (in-place collapse for partitions of > 128 records)" : "k_insert", n_huge);
         if (n_huge) {
             hipLaunchKernelGGL(k_insert_huge, dim3(std::min<u32>(n_huge, 256u)), dim3(HG_THREADS), 0, h->stream, P, src, (const PartDesc*)h->desc.p, (const u32*)h->huge.p + 1,
                                (const u32*)h->huge.p, h->ix);
@@ -835,6 +841,7 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
             tags = (u32*)h->tags_a.p;
         }
         rc = scan_impl(h, d_packed, d_starts, n_reads, (u64*)h->staging.p, cap, with_hist, query_mode, tags, n_rec_out, nullptr, bound, hist_valid);
+        if (rc == BRISK_HIP_OK && h->verify && !query_mode) return verify_records(h, (const u64*)h->staging.p, *n_rec_out, bound, "scan to staging");
         if (rc != BRISK_HIP_ECAPACITY) return rc;
         cap = bound;
     }
@@ -889,6 +896,7 @@ int scan_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     if ((u32)h->h_small[1]) return BRISK_HIP_OK;  // more records beyond the bins than the overflow buffer holds: the classic path takes the batch
     *n_rec_out = h->h_small[0];
     *bl = BinLayout{(u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, h->h_small[7], tags};
+    if (h->verify && !query_mode && (rc = verify_hist(h, h->h_small[0], bound, "binned scan"))) return rc;
     *applied = true;
     return BRISK_HIP_OK;
 }
@@ -927,6 +935,7 @@ int flush_pending(brisk_hip_index* h) {
     if (!h->n_pend) return BRISK_HIP_OK;
     const u64 n = h->n_pend;
     const bool hist_ok = h->pend_hist_ok;
+    if (h->trace) fprintf(stderr, "[brisk_hip] path: flush of %llu pending records\n", (unsigned long long)n);
     h->n_pend = 0;  // whatever happens, the records are consumed (a failed insert is a failed insert)
     h->pend_hist_ok = true;
     return insert_records_impl(h, (const u64*)h->pend.p, n, hist_ok);
@@ -964,7 +973,12 @@ int defer_batch(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     if (est >= (u64)DEFER_DIRECT_AT * h->n_parts) return BRISK_HIP_OK;
     for (int attempt = 0; attempt < 2; attempt++) {
         const u64 cap = attempt ? bound : est;
-        if ((rc = pend_reserve(h, cap))) return rc;
+        if ((rc = pend_reserve(h, cap))) {
+            if (rc != BRISK_HIP_ENOMEM) return rc;
+            // no room for the pending buffer: what is pending goes in now, and this batch takes the direct path, which needs none
+            h->err.clear();
+            return flush_pending(h);
+        }
         u64 n_rec = 0;
         bool hist_ok = true;
         const bool with_hist = h->pend_hist_ok;
@@ -976,7 +990,10 @@ int defer_batch(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
             continue;
         }
         if (rc) return rc;
+        if (h->verify && (rc = verify_records(h, (const u64*)h->pend.p + h->n_pend * h->P.stride, n_rec, bound, "deferred scan"))) return rc;
         if (!with_hist || !hist_ok) h->pend_hist_ok = false;
+        if (h->trace) fprintf(stderr, "[brisk_hip] path: deferred scan of %llu reads (attempt %d): %llu records behind %llu pending ones, histogram %s\n", (unsigned long long)n_reads, attempt,
+                              (unsigned long long)n_rec, (unsigned long long)h->n_pend, h->pend_hist_ok ? "kept" : "to be recounted");
         h->n_pend += n_rec;
         *deferred = true;
         if (h->n_pend >= (u64)DEFER_FLUSH_AT * h->n_parts) return flush_pending(h);
@@ -998,6 +1015,7 @@ int insert_packed_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_sta
         if (done) continue;
         if ((rc = flush_pending(h))) return rc;  // (the direct paths use d_hist)
         if ((rc = insert_packed_binned(h, d_packed, d_starts + r0, nb, &done))) return rc;
+        if (h->trace) fprintf(stderr, "[brisk_hip] path: direct insert of %llu reads, %s\n", (unsigned long long)nb, done ? "records binned by the scan" : "records to staging, then k_scatter");
         if (done) continue;
         bool hist_ok = true;
         if ((rc = scan_to_staging(h, d_packed, d_starts + r0, nb, true, false, &n_rec, &hist_ok))) return rc;
@@ -1195,6 +1213,82 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
     return BRISK_HIP_OK;
 }
 
+// ---- BRISK_VERIFY=1: stage checks of the host input path ---------------------------------------------------------------------
+// Round 2's parity soak saw four wrong indexes in ~49,000 cases.  The one that was recorded (tests/fuzz_parity.py as it ran then,
+// seed 102 case 739; tools/replay_fuzz_case.py rebuilds its inputs bit for bit on the CPU) is reproduced EXACTLY -- entry count,
+// bucket count, every reported entry -- by changing ONE nucleotide of ONE read of the input (read 292, offset 843, T -> A: bit 25
+// of word 4839 of the packed stream cleared, or the ASCII byte behind it) and by no change downstream of the scan: the 26 wrong
+// k-mers are all the k-mers of that read that cover the nucleotide, spread over three super-k-mers, so the scan's step loop and
+// its record builder both read the same wrong value.  The fault therefore lies between the caller's buffer and the packed stream
+// the scan reads (host -> device copy, the ASCII staging buffer, k_pack_ascii's store, the packed words until the scan is done),
+// not in the scan, the record hand-over or the insert.  These checks name the sub-stage should it happen again:
+//   verify_upload   the packed stream on the device against the caller's bytes packed on the host; on a mismatch the ASCII staging
+//                   buffer is compared with the caller's bytes too (copy or staging memory vs pack kernel or packed memory), and
+//                   the word is read a second time (a value that changes between two reads was never stored wrong);
+//                   run before the scan and again after the body (the stream must not change while it is being scanned)
+//   verify_records  sum over a scan's records of their k-mer counts == the batch's k-mer instances (insert-mode scans)
+static u32 host_pack16(const char* s, u64 n) {  // nuc2int (Kmers.cpp:442-444) over up to 16 bytes, first nt in the top bits, zero padded
+    u32 v = 0;
+    for (u64 i = 0; i < 16; i++) v = (v << 2) | (i < n ? (((uint8_t)s[i] >> 1) & 3u) : 0u);
+    return v;
+}
+int verify_upload(brisk_hip_index* h, const char* src, u64 nb, const u32* d_packed, u64 n_words, const char* when) {
+    if (!n_words) return BRISK_HIP_OK;
+    std::vector<u32> dev(n_words);
+    HIPCHK(h, hipMemcpy(dev.data(), d_packed, n_words * 4, hipMemcpyDeviceToHost));
+    for (u64 w = 0; w < n_words; w++) {
+        const u32 want = host_pack16(src + w * 16, nb - w * 16);
+        if (dev[w] == want) continue;
+        u32 again = 0;
+        HIPCHK(h, hipMemcpy(&again, d_packed + w, 4, hipMemcpyDeviceToHost));
+        std::string msg = std::string("BRISK_VERIFY: packed stream differs from the caller's bytes ") + when + ": word " + std::to_string(w) + " of " + std::to_string(n_words) +
+                          ": host " + std::to_string(want) + ", device " + std::to_string(dev[w]) + ", device read again " + std::to_string(again);
+        // the ASCII staging buffer still holds this batch when the input went in one piece (upload_and_pack); the lanes' chunk buffers do not
+        if (h->bases_tmp.p && h->bases_tmp.bytes >= nb && (nb + kUploadChunk - 1) / kUploadChunk < 4) {
+            const u64 b0 = w * 16, bn = std::min<u64>(16, nb - b0);
+            char a[17] = {0};
+            HIPCHK(h, hipMemcpy(a, (const char*)h->bases_tmp.p + b0, bn, hipMemcpyDeviceToHost));
+            const bool ascii_ok = memcmp(a, src + b0, bn) == 0;
+            msg += std::string("; ASCII staging bytes ") + (ascii_ok ? "EQUAL the caller's: the pack kernel's store or the packed words are at fault"
+                                                                     : "DIFFER from the caller's: the host->device copy or the staging memory is at fault") +
+                   " (device \"" + std::string(a, bn) + "\", host \"" + std::string(src + b0, bn) + "\")";
+        }
+        u64 n_bad = 0;
+        for (u64 x = w; x < n_words; x++) n_bad += dev[x] != host_pack16(src + x * 16, nb - x * 16);
+        msg += "; " + std::to_string(n_bad) + " words differ in all";
+        fprintf(stderr, "[brisk_hip] %s\n", msg.c_str());
+        return fail(h, BRISK_HIP_EHIP, msg);
+    }
+    return BRISK_HIP_OK;
+}
+// sum of hdr_n over n_rec records laid out back to back == want (insert-mode scans: every k-mer instance of the batch is in exactly one record)
+int verify_records(brisk_hip_index* h, const u64* d_rec, u64 n_rec, u64 want, const char* what) {
+    std::vector<u64> hdr(n_rec);
+    if (n_rec) HIPCHK(h, hipMemcpy2D(hdr.data(), 8, d_rec + h->P.nw, h->P.stride * 8, 8, n_rec, hipMemcpyDeviceToHost));
+    u64 sum = 0;
+    for (u64 i = 0; i < n_rec; i++) sum += (hdr[i] >> 32) & 0xff;
+    if (sum == want) return BRISK_HIP_OK;
+    const std::string msg = std::string("BRISK_VERIFY: ") + what + ": the records hold " + std::to_string(sum) + " k-mers, the batch has " + std::to_string(want);
+    fprintf(stderr, "[brisk_hip] %s\n", msg.c_str());
+    return fail(h, BRISK_HIP_EHIP, msg);
+}
+
+// the per-partition histogram a scan left in d_hist: records and k-mer instances add up to what the scan reported / the batch holds
+int verify_hist(brisk_hip_index* h, u64 want_rec, u64 want_inst, const char* what) {
+    std::vector<unsigned long long> hist(h->n_parts);
+    HIPCHK(h, hipMemcpy(hist.data(), h->d_hist, h->n_parts * 8, hipMemcpyDeviceToHost));
+    u64 rec = 0, inst = 0;
+    for (unsigned long long v : hist) {
+        rec += v & 0xffffffffull;
+        inst += v >> 32;
+    }
+    if (rec == want_rec && inst == want_inst) return BRISK_HIP_OK;
+    const std::string msg = std::string("BRISK_VERIFY: ") + what + ": the histogram counts " + std::to_string(rec) + " records / " + std::to_string(inst) +
+                            " k-mers, expected " + std::to_string(want_rec) + " / " + std::to_string(want_inst);
+    fprintf(stderr, "[brisk_hip] %s\n", msg.c_str());
+    return fail(h, BRISK_HIP_EHIP, msg);
+}
+
 // host ASCII reads -> device packed stream + starts, in pieces of at most max_bases
 template <class F>
 int for_each_host_batch(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads, F&& body) {
@@ -1221,10 +1315,15 @@ int for_each_host_batch(brisk_hip_index* h, const char* bases, const uint64_t* o
         const auto t_a = std::chrono::steady_clock::now();
         if ((rc = upload_and_pack(h, bases + offsets[r0], nb, (u32*)h->packed_tmp.p, n_words))) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->verify && (rc = verify_upload(h, bases + offsets[r0], nb, (const u32*)h->packed_tmp.p, n_words, "before the scan"))) return rc;
         if (dbg_up) fprintf(stderr, "[brisk_hip] upload: %llu bases in %.1f ms (offsets prepared in %.1f ms)\n", (unsigned long long)nb,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count(),
                             std::chrono::duration<double, std::milli>(t_a - t_0).count());
         if ((rc = body(r0, nr))) return rc;
+        if (h->verify) {  // the packed stream must not have changed while it was scanned
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if ((rc = verify_upload(h, bases + offsets[r0], nb, (const u32*)h->packed_tmp.p, n_words, "after the scan"))) return rc;
+        }
         r0 = r1;
     }
     return BRISK_HIP_OK;
@@ -1355,6 +1454,12 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
     h->entry_ids = o.entry_ids != 0;
     static const bool defer_env = !(getenv("BRISK_DEFER") && atoi(getenv("BRISK_DEFER")) == 0);  // BRISK_DEFER=0: every insert call completes before it returns
     h->defer = defer_env && !o.immediate_inserts;
+    {   // read per handle, not once per process: a soak switches it case by case
+        const char* v = getenv("BRISK_VERIFY");
+        h->verify = v && v[0] == '1';
+        const char* t = getenv("BRISK_TRACE");
+        h->trace = t && t[0] == '1';
+    }
     h->device = o.device;
 
     auto init = [&]() -> int {
@@ -1755,7 +1860,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (memory_bytes) {
         u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
         for (const DevBuf* b : {&h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
-                                &h->enum_out, &h->lookup_buf})
+                                &h->enum_out, &h->lookup_buf, &h->pend, &h->huge, &h->seq_buf})
             m += b->bytes;
         *memory_bytes = m;
     }
@@ -1773,8 +1878,9 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
 // merge, their counts added mod 256.  `from` is left untouched.
 BRISK_API int brisk_hip_reallocate(brisk_hip_index* from, brisk_hip_index* to) {
     if (!from || !to || from == to) return BRISK_HIP_EINVAL;
-    std::lock_guard<std::recursive_mutex> lock_from(from->call_mu);
-    std::lock_guard<std::recursive_mutex> call_lock(to->call_mu);
+    std::lock(from->call_mu, to->call_mu);  // both or neither: reallocate(a, b) and reallocate(b, a) from two threads must not wait for each other
+    std::lock_guard<std::recursive_mutex> lock_from(from->call_mu, std::adopt_lock);
+    std::lock_guard<std::recursive_mutex> call_lock(to->call_mu, std::adopt_lock);
     brisk_hip_index* h = to;
     if (from->P.k != to->P.k || from->device != to->device) return fail(h, BRISK_HIP_EINVAL, "reallocate: both indexes must have the same k and device");
     if (from->entry_ids || to->entry_ids) return fail(h, BRISK_HIP_EINVAL, "reallocate: entry-id indexes are re-bucketed by the facade (DATA lives on the host)");
@@ -1782,6 +1888,12 @@ BRISK_API int brisk_hip_reallocate(brisk_hip_index* from, brisk_hip_index* to) {
     HIPCHK(h, hipSetDevice(h->device));
     if (int frc = enter(from)) return fail(h, frc, "reallocate: " + from->err);
     if (int frc = enter(to)) return frc;
+    {   // `to` must be empty (the reference re-buckets into a fresh DenseMenuYo, brisk/Brisk.hpp:205): counts would silently merge otherwise
+        unsigned long long used = 0;
+        HIPCHK(h, hipMemcpyAsync(&used, to->ix.cursor, 8, hipMemcpyDeviceToHost, to->stream));
+        HIPCHK(h, hipStreamSynchronize(to->stream));
+        if (used || to->arena_used_host || to->nb_skmers) return fail(h, BRISK_HIP_EINVAL, "reallocate: the target index is not empty");
+    }
     HIPCHK(h, hipStreamSynchronize(from->stream));
     const u32 k = from->P.k;
     // the old index's partition sizes

@@ -543,18 +543,22 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                         if (P.stride > 3) dst[3] = rr.w3;
                         if (P.stride > 4) dst[4] = rr.w4;
                     }
-                    const bool dup = dedupe_records(P.stride, rr, 1u, avail, lane, s_rec, s_rtab, s_rmult);
+                    // a record may carry a multiplicity already (brisk_hip_reallocate: one k-mer with its entry's count): it is what
+                    // the record adds to its survivor, and it is replaced, not OR-ed over, in the survivor's header
+                    const u64 hdr_c = P.stride == 2 ? rr.w1 : P.stride == 3 ? rr.w2 : P.stride == 4 ? rr.w3 : rr.w4;
+                    const u32 mult_c = (hdr_c & HDR_HAS_MULT) ? (u32)(hdr_c >> 48) & 0xffu : 1u;
+                    const bool dup = dedupe_records(P.stride, rr, mult_c, avail, lane, s_rec, s_rtab, s_rmult);
                     wave_sync();
                     const bool keep = lane < avail && !dup;
                     const unsigned long long bal = __ballot(keep);
                     if (keep) {  // survivors move to the front of the partition's records (never past what is still to be read)
                         u64* dst = rec + (u64)(wr + (u32)__popcll(bal & lanes_below(lane))) * P.stride;
-                        const u64 mult = ((u64)(s_rmult[lane] & 0xffu) << 48) | HDR_HAS_MULT;
+                        const u64 keep_id = HDR_ID_MASK, mult = ((u64)(s_rmult[lane] & 0xffu) << 48) | HDR_HAS_MULT;
                         dst[0] = rr.w0;
-                        dst[1] = P.stride == 2 ? rr.w1 | mult : rr.w1;
-                        if (P.stride > 2) dst[2] = P.stride == 3 ? rr.w2 | mult : rr.w2;
-                        if (P.stride > 3) dst[3] = P.stride == 4 ? rr.w3 | mult : rr.w3;
-                        if (P.stride > 4) dst[4] = rr.w4 | mult;
+                        dst[1] = P.stride == 2 ? (rr.w1 & keep_id) | mult : rr.w1;
+                        if (P.stride > 2) dst[2] = P.stride == 3 ? (rr.w2 & keep_id) | mult : rr.w2;
+                        if (P.stride > 3) dst[3] = P.stride == 4 ? (rr.w3 & keep_id) | mult : rr.w3;
+                        if (P.stride > 4) dst[4] = (rr.w4 & keep_id) | mult;
                     }
                     wr += (u32)__popcll(bal);
                 }

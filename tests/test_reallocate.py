@@ -49,8 +49,11 @@ def _lines_to_counter(lines):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,m,b", [(31, 11, 4), (63, 21, 14), (41, 15, 10)])
-def test_bulk_reallocate_matches_the_enumerator_at_the_new_m(O, k, m, b):
+@pytest.mark.parametrize("k,m,b,pb", [(31, 11, 4, 0), (63, 21, 14, 0), (41, 15, 10, 0),
+                                      # few partitions in the target: more than 128 one-k-mer records per partition, each with its entry's
+                                      # count in the header -- k_insert_big's in-place collapse must add those counts up, not count the records
+                                      (31, 11, 4, 4), (41, 15, 10, 3)])
+def test_bulk_reallocate_matches_the_enumerator_at_the_new_m(O, k, m, b, pb):
     import brisk_amd
     rng = random.Random(77)
     genome = "".join(rng.choice("ACGT") for _ in range(6000))
@@ -60,9 +63,10 @@ def test_bulk_reallocate_matches_the_enumerator_at_the_new_m(O, k, m, b):
         s = genome[p:p + 150]
         reads.append(s if rng.random() < 0.5 else "".join(COMP[c] for c in reversed(s)))
     reads += ["A" * 120, "ACGT" * 40, "AC" * 70]  # low complexity: minimizer ties, entries that merge
-    with brisk_amd.BriskHip(k, m, b) as old, brisk_amd.BriskHip(k, m + 2, b + 2) as new:
+    with brisk_amd.BriskHip(k, m, b) as old, brisk_amd.BriskHip(k, m + 2, b + 2, part_bits=pb) as new:
         old.insert_reads(reads)
         before = oracle.multiset_lines(*old.enumerate(), k)
+        assert max(int(l.split()[-1]) for l in before) > 20  # counts well above 1, even and odd
         old.reallocate_into(new)
         after = oracle.multiset_lines(*new.enumerate(), k)
         assert oracle.multiset_lines(*old.enumerate(), k) == before, "the source index must stay as it is"
