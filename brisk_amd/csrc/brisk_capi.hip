@@ -88,6 +88,7 @@ struct brisk_hip_index {
     bool verify = false;        // BRISK_VERIFY=1 at create: every stage hand-over of the host paths is checked (verify_upload, verify_records)
     bool trace = false;         // BRISK_TRACE=1 at create: one stderr line per batch saying which host path and which insert kernel took it
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
+    u32* d_ovf_cnt = nullptr;              // OVF_REGIONS counters of the binned scan's overflow area
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
     u32* d_cur32 = nullptr;                // n_parts
@@ -447,6 +448,8 @@ struct BinLayout {
     u32 bin_cap;
     u64* ovf;
     u64 n_ovf;
+    const u32* ovf_cnt;   // the overflow area's region counters (ScanOut::ovf_cnt) and the slots per region
+    u32 ovf_region_cap;
     const u32* tags;  // query mode: the read of every record, laid out like the records: [n_parts * bin_cap] binned, then the overflow records'
 };
 int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool have_hist, const BinLayout* bl = nullptr);
@@ -494,8 +497,9 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
     if (n_move) {
         if ((rc = ensure(h, h->parted, n_move * P.stride * 8))) return rc;
         ProfScope ps(h, S_SCATTER);
-        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_move, 256)), dim3(256), 0, h->stream, P, bl ? (const u64*)bl->ovf : d_rec, n_move, h->d_cur32, (u64*)h->parted.p, 0,
-                           (const u32*)nullptr, (u32*)nullptr, h->ix.err);
+        const u64 n_slots = bl ? (u64)bl->ovf_region_cap * OVF_REGIONS : n_move;  // (the overflow area is scattered slot by slot: its regions are filled to different levels)
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_slots, 256)), dim3(256), 0, h->stream, P, bl ? (const u64*)bl->ovf : d_rec, n_move, h->d_cur32, (u64*)h->parted.p, 0,
+                           (const u32*)nullptr, (u32*)nullptr, h->ix.err, bl ? bl->ovf_cnt : (const u32*)nullptr, bl ? bl->ovf_region_cap : 0u);
         if ((rc = launch_check(h, "k_scatter"))) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
@@ -648,7 +652,7 @@ int scan_impl(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u64 
         if (!keep_hist) HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));  // (keep_hist: add to the pending records' counts)
     }
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
-    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret, nullptr, 0u, nullptr, 0ull, nullptr};
+    ScanOut out{d_rec, cap, h->d_small, with_hist ? h->d_hist : nullptr, (u32*)(h->d_small + 1), d_tags, d_ret, nullptr, 0u, nullptr, 0u, nullptr};
     const bool plain = h->scan_v1 || d_ret;
     int rc;
     u32 n_vr = 0;
@@ -875,7 +879,9 @@ int scan_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     const u64 bytes = h->n_parts * cap * h->P.stride * 8;
     if (forced <= 0 && (est < 2 * h->n_parts || cap > 64 || bytes > total_b / 4)) return BRISK_HIP_OK;  // sparse batch, big partitions, or too much memory
     if (h->n_parts * cap >= (1ull << 32)) return BRISK_HIP_OK;
-    const u64 ovf_cap = est / 8 + 65536;
+    // (tests force tiny bins: most records lie beyond them, and the regions -- filled by the low bits of the partition -- are uneven when partitions are few)
+    const u32 ovf_region_cap = (u32)(((forced > 0 ? 4 * est : est / 8) + 65536 + OVF_REGIONS - 1) / OVF_REGIONS);
+    const u64 ovf_cap = (u64)ovf_region_cap * OVF_REGIONS;
     if ((rc = ensure(h, h->bins, bytes))) return rc == BRISK_HIP_ENOMEM ? (h->err.clear(), BRISK_HIP_OK) : rc;
     if ((rc = ensure(h, h->staging, ovf_cap * h->P.stride * 8))) return rc;
     u32* tags = nullptr;
@@ -887,15 +893,20 @@ int scan_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small, 0, 16, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small + 7, 0, 8, h->stream));
-    ScanOut out{nullptr, 0, h->d_small, h->d_hist, (u32*)(h->d_small + 1), tags, nullptr, (u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, ovf_cap, h->d_small + 7};
+    HIPCHK(h, hipMemsetAsync(h->d_ovf_cnt, 0, OVF_REGIONS * 4, h->stream));
+    ScanOut out{nullptr, 0, h->d_small, h->d_hist, (u32*)(h->d_small + 1), tags, nullptr, (u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, ovf_region_cap, h->d_ovf_cnt};
     ChunkCtl cc{nullptr, nullptr, nullptr, 0u};
     if ((rc = launch_scan(h, d_packed, d_starts, n_reads, out, query_mode, false, cc))) return rc;
+    hipLaunchKernelGGL(k_sum_regions, dim3(1), dim3(1024), 0, h->stream, h->d_ovf_cnt, ovf_region_cap, h->d_small + 7);
+    if ((rc = launch_check(h, "k_sum_regions"))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_small, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_small + 7, h->d_small + 7, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if ((u32)h->h_small[1]) return BRISK_HIP_OK;  // more records beyond the bins than the overflow buffer holds: the classic path takes the batch
     *n_rec_out = h->h_small[0];
-    *bl = BinLayout{(u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, h->h_small[7], tags};
+    if (h->trace) fprintf(stderr, "[brisk_hip] path: binned scan of %llu reads: %llu records, bins of %llu, %llu records beyond their bins\n", (unsigned long long)n_reads,
+                          (unsigned long long)h->h_small[0], (unsigned long long)cap, (unsigned long long)h->h_small[7]);
+    *bl = BinLayout{(u64*)h->bins.p, (u32)cap, (u64*)h->staging.p, h->h_small[7], h->d_ovf_cnt, ovf_region_cap, tags};
     if (h->verify && !query_mode && (rc = verify_hist(h, h->h_small[0], bound, "binned scan"))) return rc;
     *applied = true;
     return BRISK_HIP_OK;
@@ -1062,8 +1073,9 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
         ProfScope ps(h, S_SCATTER);
         if ((rc = ensure(h, h->parted, n_move * P.stride * 8))) return rc;
         if ((rc = ensure(h, h->tags_b, n_move * 4))) return rc;
-        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_move, 256)), dim3(256), 0, h->stream, P, bl ? (const u64*)bl->ovf : d_rec, n_move, h->d_cur32, (u64*)h->parted.p, 0,
-                           bl ? bl->tags + h->n_parts * bl->bin_cap : d_tags, (u32*)h->tags_b.p, h->ix.err);
+        const u64 n_slots = bl ? (u64)bl->ovf_region_cap * OVF_REGIONS : n_move;
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(n_slots, 256)), dim3(256), 0, h->stream, P, bl ? (const u64*)bl->ovf : d_rec, n_move, h->d_cur32, (u64*)h->parted.p, 0,
+                           bl ? bl->tags + h->n_parts * bl->bin_cap : d_tags, (u32*)h->tags_b.p, h->ix.err, bl ? bl->ovf_cnt : (const u32*)nullptr, bl ? bl->ovf_region_cap : 0u);
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 2, h->d_small + 2, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_small + 5, h->ix.cursor, 8, hipMemcpyDeviceToHost, h->stream));  // arena slots handed out so far
@@ -1369,6 +1381,7 @@ void free_all(brisk_hip_index* h) {
     fr(h->ix.slot_cur);
     fr(h->ix.slot_end);
     fr(h->d_hist);
+    fr(h->d_ovf_cnt);
     fr(h->d_off);
     fr(h->d_cur32);
     fr(h->d_touched);
@@ -1561,6 +1574,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMemsetAsync(h->ix.stats, 0, 64, h->stream));
         HIPCHK(h, hipMemsetAsync(h->ix.bucket_bits, 0, bit_words * 4, h->stream));
         HIPCHK(h, hipMalloc((void**)&h->d_hist, (np + 1) * 8));
+        HIPCHK(h, hipMalloc((void**)&h->d_ovf_cnt, OVF_REGIONS * 4));
         HIPCHK(h, hipMalloc((void**)&h->d_off, (np + 1) * 4));
         HIPCHK(h, hipMalloc((void**)&h->d_cur32, np * 4));
         HIPCHK(h, hipMalloc((void**)&h->d_touched, np * 4));

@@ -318,6 +318,20 @@ __global__ void __launch_bounds__(256) k_sum_slices(const unsigned long long* __
     __syncthreads();
     if (threadIdx.x == 0 && (s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3])) atomicAdd(n_rec_total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
+// the records in the scan's overflow regions -> *out
+__global__ void __launch_bounds__(1024) k_sum_regions(const u32* __restrict__ cnt, u32 region_cap, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s[16];
+    unsigned long long acc = 0;
+    for (u32 i = threadIdx.x; i < OVF_REGIONS; i += 1024) acc += min(cnt[i], region_cap);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; i++) t += s[i];
+        *out = t;
+    }
+}
 __global__ void __launch_bounds__(256) k_rebase(u64* __restrict__ v, u64 n, u64 base) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] -= base;
@@ -332,11 +346,16 @@ __global__ void __launch_bounds__(256) k_part_hist(BriskParams P, const u64* __r
     const u64 hdr = rec[i * P.stride + P.nw];
     atomicAdd(&hist[hdr_bucket(hdr) >> P.shift], 1ull | ((unsigned long long)hdr_n(hdr) << 32));
 }
+// region_cnt != null: `rec` is the scan's overflow area -- OVF_REGIONS regions of region_cap slots, region g filled up to region_cnt[g]
+// (ScanOut) -- and n_rec the records in it; the launch covers every slot.  Null: n_rec records back to back.
 __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u32* __restrict__ cursor,
                                                  u64* __restrict__ out, int by_owner, const u32* __restrict__ tag_in, u32* __restrict__ tag_out,
-                                                 u32* __restrict__ err) {
+                                                 u32* __restrict__ err, const u32* __restrict__ region_cnt = nullptr, u32 region_cap = 0) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rec) return;
+    if (region_cnt) {
+        const u64 reg = i / region_cap;
+        if (reg >= OVF_REGIONS || i - reg * region_cap >= min(region_cnt[reg], region_cap)) return;
+    } else if (i >= n_rec) return;
     const u64* src = rec + i * P.stride;
     const u64 hdr = src[P.nw];
     u32 bin = hdr_bucket(hdr) >> P.shift;

@@ -113,9 +113,14 @@ struct ScanOut {
     u64* bins;
     u32 bin_cap;
     u64* ovf;
-    u64 ovf_cap;
-    unsigned long long* n_ovf;
+    // the records beyond their bins: OVF_REGIONS regions of ovf_region_cap slots, each filled through its own counter.  One counter
+    // for all of them was a same-address atomic WITH a return value per record: at k31 m15 b14 -- minimizers are the smallest hashes
+    // of their windows and a partition is the TOP 24 bits of the hash there, so the partitions' loads are skewed and 3.7 % of the
+    // records lie beyond a bin of twice the mean -- those 9.7 M serialised atomics were 21 of the scan's 43 ms per 20 M reads.
+    u32 ovf_region_cap;
+    u32* ovf_cnt;
 };
+#define OVF_REGIONS 4096u   // a record's region: the low bits of its partition
 
 struct MiniState {
     u64 mini;
@@ -177,35 +182,67 @@ __device__ __forceinline__ u32 superkmer_pieces(const BriskParams& P, u32 n, u32
     return (CLS ? P.cls_bits : 0u) ? cls_of(P, idx_end) - cls_of(P, idx_end - (n - 1)) + 1 : 1u;
 }
 
+// ---- a super-k-mer's nucleotides as one wide value: 256 bits in general (2k-m <= 125 nts), 128 bits where 2k-m <= 64 (k <= 32 with
+// the usual m: half the shifts and masks of the record builder, which is most of the scan at short k -- 13 records per 150-bp read
+// at k31 m15 against 3.2 at k63 m21)
+__device__ __forceinline__ W4 x_shr(W4 a, u32 s) { return w4_shr(a, s); }
+__device__ __forceinline__ W4 x_shl(W4 a, u32 s) { return w4_shl(a, s); }
+__device__ __forceinline__ W4 x_and(W4 a, W4 b) { return w4_and(a, b); }
+__device__ __forceinline__ W4 x_andn(W4 a, W4 b) { return w4_andn(a, b); }
+__device__ __forceinline__ W4 x_or(W4 a, W4 b) { return w4_or(a, b); }
+__device__ __forceinline__ W4 x_xor(W4 a, W4 b) { return W4{a.w0 ^ b.w0, a.w1 ^ b.w1, a.w2 ^ b.w2, a.w3 ^ b.w3}; }
+__device__ __forceinline__ W4 x_rc(W4 a, u32 len) { return w4_rc(a, len); }
+__device__ __forceinline__ u64 x_w0(W4 a) { return a.w0; }
+__device__ __forceinline__ u64 x_word(W4 a, u32 i) { return i == 0 ? a.w0 : i == 1 ? a.w1 : i == 2 ? a.w2 : a.w3; }
+__device__ __forceinline__ u128x x_shr(u128x a, u32 s) { return shr128(a, s); }
+__device__ __forceinline__ u128x x_shl(u128x a, u32 s) { return shl128(a, s); }
+__device__ __forceinline__ u128x x_and(u128x a, u128x b) { return and128(a, b); }
+__device__ __forceinline__ u128x x_andn(u128x a, u128x b) { return andn128(a, b); }
+__device__ __forceinline__ u128x x_or(u128x a, u128x b) { return or128(a, b); }
+__device__ __forceinline__ u128x x_xor(u128x a, u128x b) { return u128x{a.lo ^ b.lo, a.hi ^ b.hi}; }
+__device__ __forceinline__ u128x x_rc(u128x a, u32 len) {  // true reverse complement of a len-nt value, len in [1,64]
+    const u64 c = 0xaaaaaaaaaaaaaaaaull;
+    return shr128(u128x{rev_nts64(a.hi ^ c), rev_nts64(a.lo ^ c)}, 128 - 2 * len);
+}
+__device__ __forceinline__ u64 x_w0(u128x a) { return a.lo; }
+__device__ __forceinline__ u64 x_word(u128x a, u32 i) { return i == 0 ? a.lo : i == 1 ? a.hi : 0ull; }
+template <class T> __device__ __forceinline__ T x_mask(u32 bits);
+template <> __device__ __forceinline__ W4 x_mask<W4>(u32 bits) { return w4_mask(bits); }
+template <> __device__ __forceinline__ u128x x_mask<u128x>(u32 bits) { return mask128(bits); }
+template <class T> __device__ __forceinline__ T x_from64(u64 v);
+template <> __device__ __forceinline__ W4 x_from64<W4>(u64 v) { return W4{v, 0, 0, 0}; }
+template <> __device__ __forceinline__ u128x x_from64<u128x>(u64 v) { return u128x{v, 0}; }
+template <class T> __device__ __forceinline__ T x_load(const u32* __restrict__ packed, u64 q, u32 len);
+template <> __device__ __forceinline__ W4 x_load<W4>(const u32* __restrict__ packed, u64 q, u32 len) { return load_span(packed, q, len); }
+template <> __device__ __forceinline__ u128x x_load<u128x>(const u32* __restrict__ packed, u64 q, u32 len) {  // len in [1,64]
+    const u32 c = len >= 32 ? 32 : len;
+    u128x r{load_nts(packed, q + len - c, c), 0};
+    if (len > 32) r.hi = load_nts(packed, q, len - 32);
+    return r;
+}
+
 // Build and append the record(s) of one super-k-mer: k-mers at read positions
 // [p0, p0+n), vector reversed if `rev` (Kmers.cpp:554-556,597-599); idx_end is
 // the minimizer_idx of the LAST element of the returned vector.  `slot`: the first of superkmer_pieces() consecutive
 // slots (classic output); binned output takes its slots from the partitions' histogram counters.
-template <bool CLS>  // CLS false: the caller knows there are no minimizer_idx classes (m >= 12)
-__device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
-                               u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
-    if (!out.bins && slot + superkmer_pieces<CLS>(P, n, idx_end) > out.cap) {
-        *out.overflow = 1;
-        return;
-    }
+template <bool CLS, class T>  // CLS false: the caller knows there are no minimizer_idx classes (m >= 12); T: W4 or u128x
+__device__ __forceinline__ void emit_record_wide(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
+                                                 u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
     const u32 L = P.k + n - 1;
-    W4 S = load_span(packed, q0 + p0, L);
-    if (rev) S = w4_rc(S, L);
+    T S = x_load<T>(packed, q0 + p0, L);
+    if (rev) S = x_rc(S, L);
     // minimizer of every k-mer of the vector = the m-mer at suffix offset idx_end
     // of the last one (hash_kmer_minimizer_inplace re-extracts it, Kmers.cpp:191-200)
-    const u64 mm = w4_shr(S, 2 * idx_end).w0 & P.m_mask;
+    const u64 mm = x_w0(x_shr(S, 2 * idx_end)) & P.m_mask;
     const u64 h = mix2m(mm, P.m_mask);
     const u32 rbase = routing_base(P, h);  // Brisk.hpp:135-137, plus the extra routing bits of the hash
     // replace the minimizer by its hash (replace_slice, Kmers.cpp:149-159): both have 2m bits, so XOR-ing their difference
     // into place does it with one shift
-    {
-        const W4 d = w4_shl(W4{mm ^ h, 0, 0, 0}, 2 * idx_end);
-        S = W4{S.w0 ^ d.w0, S.w1 ^ d.w1, S.w2 ^ d.w2, S.w3 ^ d.w3};
-    }
+    S = x_xor(S, x_shl(x_from64<T>(mm ^ h), 2 * idx_end));
     // drop the b bucket nts at suffix offset idx_end + suff_reduc (get_compacted, Kmers.cpp:138-145)
     const u32 cut = idx_end + P.suff_reduc;
-    const W4 lowm = w4_mask(2 * cut);
-    const W4 C = w4_or(w4_andn(w4_shr(S, 2 * P.b), lowm), w4_and(S, lowm));
+    const T lowm = x_mask<T>(2 * cut);
+    const T C = x_or(x_andn(x_shr(S, 2 * P.b), lowm), x_and(S, lowm));
     const u32 idx_first = idx_end - (n - 1);
 
     // elements [j0, j1) of the vector share a routing id: all of them without classes
@@ -218,8 +255,8 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
         }
         const u32 np = j1 - j0;
         // the piece's compacted string: its last k-mer ends n - j1 nts before the vector's
-        W4 Cp = C;
-        if (np != n) Cp = w4_and(w4_shr(C, 2 * (n - j1)), w4_mask(2 * (P.kb + np - 1)));
+        T Cp = C;
+        if (np != n) Cp = x_and(x_shr(C, 2 * (n - j1)), x_mask<T>(2 * (P.kb + np - 1)));
         u64* r;
         if (out.bins) {
             // One pass over the records instead of two: the histogram atomic every record pays anyway returns the record's
@@ -227,27 +264,44 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
             // stores ride along with a kernel that is bound by its vector instructions; k_scatter (209 M of the same stores and
             // nothing else: 10-12 ms per 50 M reads) and the staging copy it read are gone.
             const u32 part = bucket >> P.shift;
+#ifdef SCAN_ATTR_NOATOMIC  // attribution builds: wrong results, timing only
+            const u32 rank = (part * 7u + (threadIdx.x & 63)) % out.bin_cap;
+#else
+            // (Issuing all of a flush's atomics first -- a record's partition needs its minimizer only -- and building the records afterwards
+            // was measured: 26.1 against 26.0 ms per 50 M reads at k63, 43.4 against 42.9 per 20 M at k31 m15.  What the records waited
+            // for was not this atomic but the one behind the overflow area: ScanOut::ovf_cnt.)
             const u32 rank = (u32)atomicAdd(&out.hist[part], 1ull | ((unsigned long long)np << 32));
+#endif
             if (rank < out.bin_cap) {
                 r = out.bins + ((u64)part * out.bin_cap + rank) * P.stride;
                 if (out.tag) out.tag[(u64)part * out.bin_cap + rank] = tag;  // query mode: the records' reads, laid out like the records
             } else {
-                const unsigned long long o = atomicAdd(out.n_ovf, 1ull);
-                if (o >= out.ovf_cap) {
+#ifdef SCAN_ATTR_NOOVF  // attribution builds: records beyond their bin are dropped
+                return;
+#endif
+                const u32 reg = part & (OVF_REGIONS - 1);
+                const u32 at = atomicAdd(&out.ovf_cnt[reg], 1u);
+                if (at >= out.ovf_region_cap) {
                     *out.overflow = 1;
                     return;
                 }
+                const u64 o = (u64)reg * out.ovf_region_cap + at;
                 r = out.ovf + o * P.stride;
                 if (out.tag) out.tag[((u64)out.bin_cap << P.part_bits) + o] = tag;
             }
         } else {
             r = out.rec + slot * P.stride;
         }
-        r[0] = Cp.w0;
-        if (P.nw > 1) r[1] = Cp.w1;
-        if (P.nw > 2) r[2] = Cp.w2;
-        if (P.nw > 3) r[3] = Cp.w3;
-        r[P.nw] = rec_header(bucket, np, idx_first + j0 + P.suff_reduc);
+#ifdef SCAN_ATTR_NOSTORE  // attribution builds: the record is computed and (practically) never stored
+        if ((x_word(Cp, 0) ^ x_word(Cp, 1)) == 0x123456789abcdefull)
+#endif
+        {
+            r[0] = x_word(Cp, 0);
+            if (P.nw > 1) r[1] = x_word(Cp, 1);
+            if (P.nw > 2) r[2] = x_word(Cp, 2);
+            if (P.nw > 3) r[3] = x_word(Cp, 3);
+            r[P.nw] = rec_header(bucket, np, idx_first + j0 + P.suff_reduc);
+        }
         if (!out.bins) {
             if (out.tag) out.tag[slot] = tag;
             if (out.ret) out.ret[slot] = ret;
@@ -256,6 +310,20 @@ __device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ pac
         slot++;
         j0 = j1;
     }
+}
+#ifndef EMIT_SMALL
+#define EMIT_SMALL 1   // 0: every span through the 256-bit path (A/B)
+#endif
+template <bool CLS>
+__device__ void emit_record_at(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
+                               u32 idx_end, const ScanOut& out, u32 tag, u64 ret, unsigned long long slot) {
+    if (!out.bins && slot + superkmer_pieces<CLS>(P, n, idx_end) > out.cap) {
+        *out.overflow = 1;
+        return;
+    }
+    // (a vector has at most k - m + 1 k-mers: its span at most 2k - m nts.  Wave-uniform; folds where k and m are constants)
+    if (EMIT_SMALL && 2 * P.k - P.m <= 64) emit_record_wide<CLS, u128x>(P, packed, q0, p0, n, rev, idx_end, out, tag, ret, slot);
+    else emit_record_wide<CLS, W4>(P, packed, q0, p0, n, rev, idx_end, out, tag, ret, slot);
 }
 __device__ void emit_record(const BriskParams& P, const u32* __restrict__ packed, u64 q0, u32 p0, u32 n, bool rev,
                             u32 idx_end, const ScanOut& out, u32 tag, u64 ret = 0) {
