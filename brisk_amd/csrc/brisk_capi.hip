@@ -362,10 +362,11 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         u64 ncap = std::max<u64>(target, 1u << 16);
         int rc;
-        if ((rc = vm_grow(h, h->vm_keys, ncap * 16))) return rc;
+        const u64 kb = 8ull * h->ix.key_words;  // bytes of a stored key
+        if ((rc = vm_grow(h, h->vm_keys, ncap * kb))) return rc;
         if ((rc = vm_grow(h, h->vm_counts, ncap))) return rc;
         if (h->entry_ids && (rc = vm_grow(h, h->vm_ids, ncap * 4))) return rc;
-        ncap = std::min<u64>(h->vm_keys.mapped / 16, h->vm_counts.mapped);
+        ncap = std::min<u64>(h->vm_keys.mapped / kb, h->vm_counts.mapped);
         if (h->entry_ids) ncap = std::min<u64>(ncap, h->vm_ids.mapped / 4);
         h->ix.keys = (u64*)h->vm_keys.base;
         h->ix.counts = (uint8_t*)h->vm_counts.base;
@@ -380,7 +381,8 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
     uint8_t* nc = nullptr;
     u32* ni = nullptr;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipError_t e = hipMalloc((void**)&nk, ncap * 16);
+    const u64 kb = 8ull * h->ix.key_words;
+    hipError_t e = hipMalloc((void**)&nk, ncap * kb);
     if (e == hipSuccess) e = hipMalloc((void**)&nc, ncap);
     if (e == hipSuccess && h->entry_ids) e = hipMalloc((void**)&ni, ncap * 4);
     if (e != hipSuccess) {
@@ -390,7 +392,7 @@ int ensure_arena(brisk_hip_index* h, u64 need_entries) {
         return fail(h, BRISK_HIP_ENOMEM, "arena growth: out of device memory");
     }
     if (h->arena_used_host) {
-        HIPCHK(h, hipMemcpyAsync(nk, h->ix.keys, h->arena_used_host * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(nk, h->ix.keys, h->arena_used_host * kb, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(nc, h->ix.counts, h->arena_used_host, hipMemcpyDeviceToDevice, h->stream));
         if (ni) HIPCHK(h, hipMemcpyAsync(ni, h->ix.ids, h->arena_used_host * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1455,6 +1457,9 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         delete h;
         return BRISK_HIP_EUNSUPPORTED;
     }
+    // an entry key of at most 64 bits is stored in one word (k31 b14: 44 bits, k31 b11: 46): 9 bytes per entry instead of 17
+    // (the kernels with compile-time geometry decide by the same formula: insert_body, k_query_fast)
+    h->ix.key_words = P.shift + 2 * P.kb + 6 <= 64 ? 1u : 2u;
     P.n_owners = o.n_owners ? o.n_owners : 1;
     P.owner_rank = o.owner_rank;
     if (P.owner_rank >= P.n_owners) { delete h; return BRISK_HIP_EINVAL; }
@@ -1872,7 +1877,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (largest_bucket) *largest_bucket = st[2];
     if (nb_skmers) *nb_skmers = h->nb_skmers;
     if (memory_bytes) {
-        u64 m = h->arena_cap * 17 + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
+        u64 m = h->arena_cap * (8ull * h->ix.key_words + 1) + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
         for (const DevBuf* b : {&h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
                                 &h->enum_out, &h->lookup_buf, &h->pend, &h->huge, &h->seq_buf})
             m += b->bytes;
@@ -1964,7 +1969,7 @@ BRISK_API int brisk_hip_memory_info(brisk_hip_index* h, uint64_t out[4]) {
     if (!h || !out) return BRISK_HIP_EINVAL;
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
     if (int frc = enter(h)) return frc;
-    out[0] = h->use_vmm ? h->vm_keys.mapped + h->vm_counts.mapped + h->vm_ids.mapped : h->arena_cap * (h->entry_ids ? 21 : 17);
+    out[0] = h->use_vmm ? h->vm_keys.mapped + h->vm_counts.mapped + h->vm_ids.mapped : h->arena_cap * (8ull * h->ix.key_words + 1 + (h->entry_ids ? 4 : 0));
     out[1] = h->use_vmm ? h->vm_keys.reserved + h->vm_counts.reserved + h->vm_ids.reserved : 0;
     out[2] = pool_bytes();
     out[3] = g_retired_va.load();

@@ -59,7 +59,33 @@ struct IndexDev {
     u32* err;                    // sticky violation bits: 1 scatter slot out of range, 2 arena exhausted, 4 chunk overflow
     u32 bits_check;              // few buckets (2b < 20): read a bucket-bitmap word before or-ing into it
     u32 huge_at;                 // partitions of more k-mer instances than this are left to k_insert_huge (0: none are)
+    u32 key_words;               // u64 words per stored key: 1 where [routing id low bits | compacted k-mer | idx'] fits 64 bits
+                                 // (shift + 2(k-b) + 6 <= 64: k31 b14, k31 b11, ...: 9 bytes per entry instead of 17), else 2
 };
+// an entry's key in the arena (KW: the word count where the caller knows it at compile time, 0: from ix)
+template <u32 KW = 0>
+__device__ __forceinline__ u128x load_key(const IndexDev& ix, unsigned long long at) {
+    if ((KW ? KW : ix.key_words) == 1) return u128x{ix.keys[at], 0};
+    return u128x{ix.keys[2 * at], ix.keys[2 * at + 1]};
+}
+template <u32 KW = 0>
+__device__ __forceinline__ void store_key(const IndexDev& ix, unsigned long long at, u64 lo, u64 hi) {
+    if ((KW ? KW : ix.key_words) == 1) {
+        ix.keys[at] = lo;
+    } else {
+        ix.keys[2 * at] = lo;
+        ix.keys[2 * at + 1] = hi;
+    }
+}
+template <u32 KW = 0>
+__device__ __forceinline__ void move_key(const IndexDev& ix, unsigned long long dst, unsigned long long src) {
+    if ((KW ? KW : ix.key_words) == 1) {
+        ix.keys[dst] = ix.keys[src];
+    } else {
+        ix.keys[2 * dst] = ix.keys[2 * src];
+        ix.keys[2 * dst + 1] = ix.keys[2 * src + 1];
+    }
+}
 
 // k_insert: ONE WAVE per partition, no workgroup barriers: every wave is an
 // independent stream of partitions, so a CU keeps ~10 of them in flight and their
@@ -403,26 +429,6 @@ __device__ __forceinline__ bool dedupe_records(u32 stride, const RecRegs& rr, u3
     return dup;
 }
 
-// a batch's work descriptors, one per lane (two 16-byte loads), and the broadcast of one of them through scalar registers
-struct BatchDescs {
-    uint4 a, b;
-};
-__device__ __forceinline__ BatchDescs load_batch_descs(const PartDesc* __restrict__ desc, u32 t) {
-    const uint4* p = reinterpret_cast<const uint4*>(desc + t);
-    return BatchDescs{p[0], p[1]};
-}
-__device__ __forceinline__ PartDesc batch_desc(const BatchDescs& m, u32 i) {  // i: wave-uniform lane index
-    PartDesc d;
-    d.part = (u32)__builtin_amdgcn_readlane((int)m.a.x, (int)i);
-    d.r_begin = (u32)__builtin_amdgcn_readlane((int)m.a.y, (int)i);
-    d.n_rec = (u32)__builtin_amdgcn_readlane((int)m.a.z, (int)i);
-    d.n_inst = (u32)__builtin_amdgcn_readlane((int)m.a.w, (int)i);
-    d.n_exist = (u32)__builtin_amdgcn_readlane((int)m.b.x, (int)i);
-    d.cap = (u32)__builtin_amdgcn_readlane((int)m.b.y, (int)i);
-    d.off = (unsigned long long)(u32)__builtin_amdgcn_readlane((int)m.b.z, (int)i) | ((unsigned long long)(u32)__builtin_amdgcn_readlane((int)m.b.w, (int)i) << 32);
-    return d;
-}
-
 // MAXI: k-mer instances per chunk.  256 (10 KB of LDS, 128 registers: 4 waves per SIMD) for the usual partitions of a
 // few hundred instances; 512 (2 waves per SIMD) when partitions are big -- few distinct minimizers, as with m <= 11 --
 // and the passes over a partition's entries saved by half as many chunks outweigh the occupancy.
@@ -443,6 +449,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
         P.shift = SHIFT;
     }
     constexpr u32 TABLE = 2 * MAXI, TS = TABLE / 64, NI = MAXI / 64;
+    constexpr u32 KW = NW ? (2 * KB + 6 + SHIFT <= 64 ? 1u : 2u) : 0u;  // words of a stored key (0: ix.key_words)
     static_assert(MAXI % 256 == 0 && MAXI <= 1024, "chunk size: whole 32-bit words of record marks per lane, 10-bit instance index");
     // LDS of one wave, one buffer cut into regions.  k_insert's throughput follows the number of resident waves almost
     // linearly (4096 -> 30.8 ms, 3072 -> 38.3, 2048 -> 54.2, 1024 -> 103.6 per 50 M reads: every wave is a serial chain of
@@ -484,18 +491,16 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
         t0 = (u32)__builtin_amdgcn_readfirstlane((int)t0);
         if (t0 >= n_touched) break;
         const u32 t_end = min(t0 + WI_BATCH, n_touched);
-        // The batch's descriptors, one per lane, stay in registers: a partition's descriptor is then eight
-        // v_readlane away (scalar registers), never a memory round trip -- and the NEXT partition's records can be
-        // requested at the top of the current one, a whole partition (several microseconds) ahead of their use.
-        // Under this kernel's own random traffic a dependent load takes 2-4 us of a partition's ~7 us.
-        const BatchDescs mine = load_batch_descs(desc, min(t0 + lane, n_touched - 1));
-        PartDesc d = batch_desc(mine, 0);
+        // A partition's descriptor comes by scalar loads (s_load_dwordx8: t and the array's address are wave-uniform, the array is
+        // read-only).  Round 2 kept the batch's 64 descriptors in registers, one per lane, and broadcast one with eight v_readlane:
+        // those were the eight registers the body spilled at 96 (10 spilled -> 3; 26.2 -> 25.9 ms per 50 M reads).
+        PartDesc d = desc[t0];
         RecRegs rr = load_part_recs(P, src, d.part, d.r_begin, d.r_begin, min(d.n_rec, (u32)WI_MAX_REC), lane);
 
         for (u32 t = t0; t < t_end; t++) {
             const u32 tn = t + 1;
             PartDesc dn{};
-            if (tn < t_end) dn = batch_desc(mine, tn - t0);
+            if (tn < t_end) dn = desc[tn];
             // The next partition's records are requested when this partition is done, into rr.  Round 2 requested them at the top
             // of the current partition, into a second set of registers: the memory counter retires loads in issue order and the
             // compiler's wait in front of the first use of rr is vmcnt(0), so every partition began by sitting out the round trip
@@ -690,8 +695,9 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                     for (u32 q = 0; q < 4; q++) {
                         const u32 e = e0 + q * 64 + lane;
                         const unsigned long long at = off + (e < n_exist ? e : 0);
-                        klo[q] = ix.keys[2 * at];
-                        khi[q] = ix.keys[2 * at + 1];
+                        const u128x kq = load_key<KW>(ix, at);
+                        klo[q] = kq.lo;
+                        khi[q] = kq.hi;
                         cnt[q] = ix.counts[at];
                     }
 #pragma unroll
@@ -789,8 +795,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                     garbage += cap;
                     cap = (u32)want;
                     for (u32 e = lane; e < n_exist; e += 64) {
-                        ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
-                        ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (off + e) + 1];
+                        move_key<KW>(ix, noff + e, off + e);
                         ix.counts[noff + e] = ix.counts[off + e];
                     }
                     off = noff;
@@ -801,8 +806,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                     for (u32 it = 0; it < NI; it++) {
                         if ((new_mask >> it) & 1) {
                             const unsigned long long at = off + n_exist + new_rank[it];
-                            ix.keys[2 * at] = li.klo[it];
-                            ix.keys[2 * at + 1] = li.khi[it];
+                            store_key<KW>(ix, at, li.klo[it], li.khi[it]);
                             ix.counts[at] = (uint8_t)(new_word[it] >> WI_CNT_SHIFT);
                             const u32 bl = P.shift ? ((u32)shr128(mk128(li.klo[it], li.khi[it]), kbits).lo & ((1u << P.shift) - 1)) : 0;
                             const u32 bb = P.shift > 6 ? (bl >> (P.shift - 6)) : bl;  // 64 bins at most
@@ -815,8 +819,7 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                         const u32 i = v & WI_IDX_MASK;
                         const u64 klo2 = s_key[2 * i], khi2 = s_key[2 * i + 1];
                         const unsigned long long at = off + n_exist + q;
-                        ix.keys[2 * at] = klo2;
-                        ix.keys[2 * at + 1] = khi2;
+                        store_key<KW>(ix, at, klo2, khi2);
                         ix.counts[at] = (uint8_t)(v >> WI_CNT_SHIFT);
                         // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here)
                         const u32 bl = P.shift ? ((u32)shr128(mk128(klo2, khi2), kbits).lo & ((1u << P.shift) - 1)) : 0;
@@ -899,7 +902,7 @@ __global__ void __launch_bounds__(256) k_bucket_bits(BriskParams P, IndexDev ix,
         const u32 cnt = ix.dir[part].cnt;
         const unsigned long long off = ix.dir[part].off;
         for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+            const u128x key = load_key(ix, off + e);
             const u32 bucket = (part << P.shift) | ((u32)shr128(key, kbits).lo & ((1u << P.shift) - 1));
             const u32 bit = 1u << (bucket & 31);
             if (!(ix.bucket_bits[bucket >> 5] & bit)) atomicOr(&ix.bucket_bits[bucket >> 5], bit);
@@ -1057,7 +1060,8 @@ __global__ void __launch_bounds__(HG_THREADS) k_insert_huge(BriskParams P, RecSr
             const u32 nkeys = s_nkeys;
             // ---- the partition's entries: the ones that are in the chunk take its multiplicity (mod 256)
             for (u32 e = tid; e < n_exist; e += HG_THREADS) {
-                const u64 klo = ix.keys[2 * (off + e)], khi = ix.keys[2 * (off + e) + 1];
+                const u128x ke = load_key(ix, off + e);
+                const u64 klo = ke.lo, khi = ke.hi;
                 u32 h = hash_key32(mk128(klo, khi)) & (HG_TAB - 1);
                 for (;;) {
                     const u32 v = s_tab[h];
@@ -1097,8 +1101,7 @@ __global__ void __launch_bounds__(HG_THREADS) k_insert_huge(BriskParams P, RecSr
                 }
                 const unsigned long long noff = s_noff;
                 for (u32 e = tid; e < n_exist; e += HG_THREADS) {
-                    ix.keys[2 * (noff + e)] = ix.keys[2 * (off + e)];
-                    ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (off + e) + 1];
+                    move_key(ix, noff + e, off + e);
                     ix.counts[noff + e] = ix.counts[off + e];
                 }
                 garbage += cap;
@@ -1115,8 +1118,7 @@ __global__ void __launch_bounds__(HG_THREADS) k_insert_huge(BriskParams P, RecSr
                 if (is_new) {
                     const unsigned long long at = off + n_exist + done + pos - 1;
                     const u64 klo = s_key[2 * q], khi = s_key[2 * q + 1];
-                    ix.keys[2 * at] = klo;
-                    ix.keys[2 * at + 1] = khi;
+                    store_key(ix, at, klo, khi);
                     ix.counts[at] = (uint8_t)(cv & HG_MULT);
                     // bucket id inside the partition: the key's top `shift` bits (<= 6 of them used here), as insert_body has it
                     const u32 bl = P.shift ? ((u32)shr128(mk128(klo, khi), kbits).lo & ((1u << P.shift) - 1)) : 0;

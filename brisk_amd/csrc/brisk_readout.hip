@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(64) k_query(BriskParams P, const u64* __restri
                 wave_sync();
                 // the partition's entries look their key up; every instance holding it gets the count
                 for (u32 e = lane; e < d.n_exist; e += 64) {
-                    const u128x key = mk128(ix.keys[2 * (d.off + e)], ix.keys[2 * (d.off + e) + 1]);
+                    const u128x key = load_key(ix, d.off + e);
                     const u32 cnt = ix.counts[d.off + e];
                     u32 h = hash_key32(key) & (WI_TABLE - 1);
                     for (;;) {
@@ -157,10 +157,9 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, c
         if (lane == 0) t0 = atomicAdd(work_counter, WI_BATCH);
         t0 = (u32)__builtin_amdgcn_readfirstlane((int)t0);
         if (t0 >= n_touched) break;
-        const BatchDescs bd = load_batch_descs(desc, min(t0 + lane, n_touched - 1));
         const u32 t_n = min((u32)WI_BATCH, n_touched - t0);
         for (u32 ti = 0; ti < t_n; ti++) {
-            const PartDesc d = batch_desc(bd, ti);
+            const PartDesc d = desc[t0 + ti];  // wave-uniform index, read-only array: scalar loads (as in insert_body)
             if (d.n_exist == 0) continue;  // nothing to find in an empty partition
             if (d.n_exist & PART_HUGE) continue;  // k_query_huge takes it
             const u32 r_end = d.r_begin + d.n_rec;
@@ -171,11 +170,11 @@ __global__ void __launch_bounds__(64) k_query_fast(BriskParams PP, RecSrc src, c
                 for (u32 w = 0; w < QF_TABLE / 64; w++) s_tab[w * 64 + lane] = EMPTY_SLOT;
                 wave_sync();
                 for (u32 e = lane; e < ne; e += 64) {
-                    const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(ix.keys + 2 * (d.off + ec + e));
-                    s_ekey[2 * e] = kv.x;
-                    s_ekey[2 * e + 1] = kv.y;
+                    const u128x kv = load_key<(2 * KB + 6 + SHIFT <= 64 ? 1u : 2u)>(ix, d.off + ec + e);
+                    s_ekey[2 * e] = kv.lo;
+                    s_ekey[2 * e + 1] = kv.hi;
                     const u32 word = e | ((u32)ix.counts[d.off + ec + e] << 16);  // table word: entry of the chunk | its count
-                    u32 h = hash_key32(mk128(kv.x, kv.y)) & (QF_TABLE - 1);
+                    u32 h = hash_key32(kv) & (QF_TABLE - 1);
                     while (atomicCAS(&s_tab[h], EMPTY_SLOT, word) != EMPTY_SLOT) h = (h + 1) & (QF_TABLE - 1);
                 }
                 for (u32 rc = d.r_begin; rc < r_end;) {
@@ -318,7 +317,8 @@ __global__ void __launch_bounds__(HG_THREADS) k_query_huge(BriskParams P, RecSrc
             for (u32 i = tid; i < HQ_TAB; i += HG_THREADS) s_tab[i] = EMPTY_SLOT;
             __syncthreads();
             for (u32 e = tid; e < ne; e += HG_THREADS) {
-                const u64 klo = ix.keys[2 * (d.off + ec + e)], khi = ix.keys[2 * (d.off + ec + e) + 1];
+                const u128x ke = load_key(ix, d.off + ec + e);
+                const u64 klo = ke.lo, khi = ke.hi;
                 s_ekey[2 * e] = klo;
                 s_ekey[2 * e + 1] = khi;
                 const u32 word = e | ((u32)ix.counts[d.off + ec + e] << 16);  // entry of the chunk | its count
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) k_checksum(BriskParams P, IndexDev ix, u3
     for (u32 part = wave; part < n_parts; part += n_waves) {
         const DirEnt de = ix.dir[part];
         for (u32 e = lane; e < de.cnt; e += 64) {
-            const u128x key = mk128(ix.keys[2 * (de.off + e)], ix.keys[2 * (de.off + e) + 1]);
+            const u128x key = load_key(ix, de.off + e);
             u32 idx;
             u128x hk = entry_hashed_kmer(P, part, key, &idx);
             const u64 mm = mix2m_inv(shr128(hk, 2 * idx).lo & P.m_mask, P.m_mask);
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64) k_enumerate(BriskParams P, IndexDev ix, u3
         const unsigned long long off = ix.dir[part].off;
         const u64 ob = out_base[pi];
         for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
-            const u128x key = mk128(ix.keys[2 * (off + e)], ix.keys[2 * (off + e) + 1]);
+            const u128x key = load_key(ix, off + e);
             u32 idx;
             u128x hk = entry_hashed_kmer(P, part, key, &idx);
             // unhash_kmer_minimizer (Kmers.cpp:178-187)
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) k_lookup(BriskParams P, IndexDev ix, cons
         const u32 cnt = ix.dir[part].cnt;
         const unsigned long long off = ix.dir[part].off;
         for (u32 e = lane; e < cnt && !found; e += 64) {
-            if (ix.keys[2 * (off + e)] == key.lo && ix.keys[2 * (off + e) + 1] == key.hi) {
+            if (eq128(load_key(ix, off + e), key)) {
                 found = true;
                 data = ix.counts[off + e];
                 if (out_id) id = ix.ids[off + e];
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const
         bool found = false;
         u32 id = 0;
         for (u32 e = lane; e < de.cnt && !found; e += 64) {
-            if (ix.keys[2 * (de.off + e)] == key.lo && ix.keys[2 * (de.off + e) + 1] == key.hi) {
+            if (eq128(load_key(ix, de.off + e), key)) {
                 found = true;
                 id = ix.ids[de.off + e];
             }
@@ -540,8 +540,7 @@ __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const
                     break;
                 }
                 for (u32 e = lane; e < de.cnt; e += 64) {
-                    ix.keys[2 * (noff + e)] = ix.keys[2 * (de.off + e)];
-                    ix.keys[2 * (noff + e) + 1] = ix.keys[2 * (de.off + e) + 1];
+                    move_key(ix, noff + e, de.off + e);
                     ix.counts[noff + e] = ix.counts[de.off + e];
                     ix.ids[noff + e] = ix.ids[de.off + e];
                 }
@@ -552,8 +551,7 @@ __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const
             if (lane == 0) {
                 const u32 nid = (u32)atomicAdd(id_counter, 1ull);
                 const unsigned long long at = de.off + de.cnt;
-                ix.keys[2 * at] = key.lo;
-                ix.keys[2 * at + 1] = key.hi;
+                store_key(ix, at, key.lo, key.hi);
                 ix.counts[at] = 0;
                 ix.ids[at] = nid;
                 ix.dir[part] = DirEnt{de.off, de.cnt + 1, de.cap};
