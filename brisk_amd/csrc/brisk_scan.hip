@@ -809,6 +809,61 @@ __device__ __forceinline__ u32 row_min_u32(u32 x) {
     return x;
 }
 
+// ---- k <= 32: the window minimum without re-scans ------------------------------------------------------------------------------
+// get_minimizer sees the whole k-mer when k <= 32 (no truncation): the re-scan at an expiry is then the minimum over the
+// last w + 1 candidates -- keys the step loop has already computed.  Per lane, the monotone queue of a sliding-window minimum, three
+// elements deep, in registers: element i = (key, step it was born at mod 256, reversed flag); keys strictly increasing from the front
+// (the current minimizer) to the back (newer candidates that can still become the minimizer once everything smaller has left the
+// window).  A new candidate removes every element with a larger key and goes to the back; at an expiry the front leaves and the next
+// element IS what the re-scan would find -- its key, its position (p - birth), its strand -- provided its key is unique in the window.
+// What three elements cannot say sends the lane to the lane-parallel re-scan, which stays exact for everything:
+//   * TRUNC: elements may be missing behind the last stored one (a fourth element was refused, or an equal key was seen).  Stored
+//     elements are always an exact prefix of the true queue; a candidate is stored behind an unknown tail only if it removes the
+//     last stored element (then it removes the tail too: the tail's keys are larger still);
+//   * TIE: a candidate equal to a stored key -- the reference's tie rules need the first AND last window holding the minimum
+//     (resolve_ties): the element is marked, never served.
+// k31 m15 b14, 20 M reads: the re-scans were 14 of the scan's 26 ms (profiles/r03_scan_attribution.txt).
+struct MinQueue {
+    u64 k0, k1, k2;  // ~0: empty (no key has class 3)
+    u32 meta;        // [0,8) [8,16) [16,24): birth steps mod 256; 24..26 reversed flags; 27..29 tie flags; 30 TRUNC
+};
+#define MQ_EMPTY (~0ull)
+#define MQ_TRUNC (1u << 30)
+__device__ __forceinline__ void mq_reset(MinQueue& q, u64 key, u32 birth, bool rv, bool trunc) {
+    q.k0 = key;
+    q.k1 = q.k2 = MQ_EMPTY;
+    q.meta = (birth & 0xffu) | (rv ? 1u << 24 : 0u) | (trunc ? MQ_TRUNC : 0u);
+}
+__device__ __forceinline__ void mq_push(MinQueue& q, u64 h, u32 step, bool rv) {
+    const bool l0 = q.k0 < h, l1 = q.k1 < h, l2 = q.k2 < h;  // a prefix: keys increase, empties are never smaller
+    const bool e0 = q.k0 == h, e1 = q.k1 == h, e2 = q.k2 == h;
+    const u32 cnt = (q.k0 != MQ_EMPTY ? 1u : 0u) + (q.k1 != MQ_EMPTY ? 1u : 0u) + (q.k2 != MQ_EMPTY ? 1u : 0u);
+    const u32 keep = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u);
+    if (e0 | e1 | e2) {  // an equal key: mark it, drop what lies behind it (larger keys), and the tail is unknown from here
+        const u32 j = e0 ? 0u : e1 ? 1u : 2u;
+        if (j < 1) q.k1 = MQ_EMPTY;
+        if (j < 2) q.k2 = MQ_EMPTY;
+        q.meta |= (1u << (27 + j)) | MQ_TRUNC;
+        return;
+    }
+    const bool store = keep < 3 && (!(q.meta & MQ_TRUNC) || keep < cnt);
+    if (!store) {
+        q.meta |= MQ_TRUNC;  // (full: the candidate joins the unknown tail; unknown tail and nothing removed: likewise)
+        return;
+    }
+    const u32 sh = 8 * keep;
+    q.meta = (q.meta & ~((0xffu << sh) | (1u << (24 + keep)) | (1u << (27 + keep)) | MQ_TRUNC)) | ((step & 0xffu) << sh) | (rv ? 1u << (24 + keep) : 0u);
+    if (keep == 0) q.k0 = h;
+    if (keep <= 1) q.k1 = keep == 1 ? h : MQ_EMPTY;
+    if (keep <= 2) q.k2 = keep == 2 ? h : MQ_EMPTY;
+}
+__device__ __forceinline__ void mq_pop_front(MinQueue& q) {
+    q.k0 = q.k1;
+    q.k1 = q.k2;
+    q.k2 = MQ_EMPTY;
+    q.meta = ((q.meta >> 8) & 0xffffu) | (((q.meta >> 25) & 3u) << 24) | (((q.meta >> 28) & 3u) << 27) | (q.meta & MQ_TRUNC);
+}
+
 #ifdef BRISK_PHASE_PROF  // debug builds only (tools/phase_profile.py): event counts of k_scan2
 __device__ unsigned long long g_scan_cnt[8];  // [0] wave-steps [1] expiries [2] re-scan rounds [3] of them with two k-mers [4] super-k-mers queued [5] flush passes
 #define SCNT(i, v) scan_cnt[i] += (v);
@@ -902,12 +957,18 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
     u64 mini_hash;
     u32 mini_pos;
     bool reversed;
+#ifndef SCAN_MINQUEUE
+#define SCAN_MINQUEUE 1   // 0: every expiry is re-scanned (A/B)
+#endif
+    const bool mq_on = SCAN_MINQUEUE && (KK ? (KK <= 32) : (k <= 32));  // wave-uniform: the window minimum from a per-lane queue (MinQueue) instead of re-scans
+    MinQueue mq{MQ_EMPTY, MQ_EMPTY, MQ_EMPTY, 0u};
     {
         const u32 Km = k - 1 - m;
         u64 best = ~0ull;
         u32 first = 0, last = 0;
         bool rf = false, rl = false;
-        for (u32 i = 0; i <= Km; i++) {
+        for (u32 ii = 0; ii <= Km; ii++) {
+            const u32 i = mq_on ? Km - ii : ii;  // (the queue takes the windows oldest first: window i of the (k-1)-mer is the candidate of step -1 - i)
             u64 key;
             bool rv;
             if (i < nlow1) {  // inside the low 64 bits; windows that stick out of them are zero-padded (F2)
@@ -924,9 +985,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
                 first = last = i;
                 rf = rl = rv;
             } else if (key == best) {
-                last = i;
-                rl = rv;
+                if (mq_on) {  // (descending i: an equal key lies at a smaller window index)
+                    first = i;
+                    rf = rv;
+                } else {
+                    last = i;
+                    rl = rv;
+                }
             }
+            if (mq_on) mq_push(mq, key, 0u - 1u - i, rv);
         }
         u32 pos;
         bool rev, need_canon;
@@ -938,12 +1005,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
         mini_hash = best;
         mini_pos = pos;
         reversed = rev;
+        // a tie among the (k-1)-mer's windows: the tie rules may have put the minimizer where the queue's front is not
+        if (mq_on && last != first) mq_reset(mq, best, 0u - 1u - pos, rev, true);
     }
     if (seeded) {  // the exact state the previous chunk had before this step
         const ChunkState st = cc.truth[vslot];
         mini_hash = st.hash;
         mini_pos = st.pos_rev & 0x7fffffffu;
         reversed = st.pos_rev >> 31;
+        if (mq_on) mq_reset(mq, mini_hash, 0u - 1u - mini_pos, reversed, true);  // (what else is in the window is not part of a chunk's state)
     }
     bool foreign = seeded;  // the vector open at a seeded start began before it: it is the previous chunk's
 
@@ -979,6 +1049,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
         const bool revf = cr < cf;
         const u64 h = order_key_fast<NCH, MM>(revf ? cr : cf, m, M, cfg, s_tabs, s_coef);
         mini_pos += act ? 1u : 0u;
+        if (mq_on) mq_push(mq, h, p, revf);
         const bool expired = act && mini_pos > w;                  // Kmers.cpp:551
         const bool newmin = act && !expired && h < mini_hash;      // Kmers.cpp:564
         const bool closed = expired || newmin;
@@ -1006,7 +1077,20 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
         // window per lane of a half-wave.  Window i of a k-mer is (low64 >> 2i) & M -- zero-padded where it
         // sticks out of the low 64 bits (F2); windows 32.. of a k > 32 are the all-A m-mer (KEY0), folded in
         // below without lanes.
-        unsigned long long need = __ballot(expired && !dead);
+        bool served = false;
+        if (mq_on && expired && mq.k0 != MQ_EMPTY && ((p - mq.meta) & 0xffu) == mini_pos) {
+            // the queue's front is the minimizer that has just left the window: what follows it is what get_minimizer would find --
+            // unless its key has an equal in the window (tie rules), or nothing follows (the queue lost track: TRUNC)
+            mq_pop_front(mq);
+            if (mq.k0 != MQ_EMPTY && !(mq.meta & (1u << 27))) {
+                mini_hash = mq.k0;
+                mini_pos = (p - mq.meta) & 0xffu;
+                reversed = (mq.meta >> 24) & 1u;
+                served = true;
+            }
+        }
+        SCNT(6, (u32)__popcll(__ballot(served)))
+        unsigned long long need = __ballot(expired && !dead && !served);
         SCNT(1, (u32)__popcll(need))
 #ifdef SCAN_ATTR_NORESCAN
         if (expired) {
@@ -1086,6 +1170,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
                     mini_hash = hmin;
                     mini_pos = pos;
                     reversed = rev;
+                    if (mq_on) mq_reset(mq, hmin, p - pos, rev, pos != 0);  // (what lies between the minimizer and now is unknown, unless it IS now)
                 }
             }
         }
@@ -1093,6 +1178,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
             mini_hash = h;
             mini_pos = 0;
             reversed = revf;
+            if (mq_on) mq_reset(mq, h, p, revf, false);  // (the push above has done the same: everything in the window is larger)
         }
         // a new vector begins with this k-mer (Kmers.cpp:578-592; a close at a seeded start is a real one)
         if (closed && (p > 0 || seeded)) p0 = p;

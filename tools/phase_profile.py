@@ -49,7 +49,7 @@ cn = ["partitions", "chunks", "record-dedupe attempts", "expand its (x64 lanes)"
 for i, n in enumerate(cn):
     print(f"{n:28s} {buf[16 + i]:14d}  per partition {buf[16 + i] / max(buf[16], 1):8.3f}")
 L.brisk_hip_debug_scan_counts(sbuf, 0)
-sn = ["wave-steps", "expiries (lanes)", "re-scan rounds", "  of them with two k-mers", "super-k-mers queued"]
+sn = ["wave-steps", "expiries re-scanned (lanes)", "re-scan rounds", "  of them with two k-mers", "super-k-mers queued", "-", "expiries served by the queue"]
 for i, n in enumerate(sn):
     print(f"k_scan2 {n:28s} {sbuf[i]:14d}  per wave-step {sbuf[i] / max(sbuf[0], 1):8.3f}  per read {sbuf[i] / reads:8.3f}")
 print(ix.stats())
