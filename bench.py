@@ -118,6 +118,10 @@ def main():
     part_bits = args.part_bits or (suggest_part_bits(b, total_reads) if N > 1 else 0)
     sc = ShardedCounter(k, m, b, rank, N, dev_index, stream, part_bits=part_bits)
     ix = sc.ix
+    # ownership (N > 1): equal partition ranges unless a scan of this rank's first reads shows the most loaded owner more than 1.3x
+    # above the mean; then every rank installs the same histogram-balanced cut points.  Once per job, before the
+    # warm-up: not part of a step.
+    cuts = sc.balance(d_packed, d_starts, min(n_reads, 2_000_000)) if N > 1 else None
 
     def one_job(profile):
         """empty index + the whole hot path over this rank's reads"""
@@ -213,7 +217,8 @@ def main():
             "config": {"workload": "%dx MI355X: %s synthetic %d bp reads %s, k=%d m=%d b=%d, uint8 counts, %gx coverage"
                                    % (N, ("%dM" % (args.reads // 1_000_000)) if args.reads >= 1_000_000 else str(args.reads), L,
                                       "per GPU" if args.scaling == "weak" else "in all", k, m, b, args.coverage),
-                       "reads_per_gpu": n_reads, "total_reads": total_reads, "part_bits": ix.layout["part_bits"], "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
+                       "reads_per_gpu": n_reads, "total_reads": total_reads, "part_bits": ix.layout["part_bits"],
+                       "ownership": ({"cut_points": "histogram-balanced" if cuts else "equal partition ranges", **getattr(sc, "owner_load", {})} if N > 1 else None), "genome_len": genome_len, "entries_per_step": entries_all / args.steps,
                        "parallelism": "bucket-range shard x%d + all-to-all" % N if N > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1,6 +1,6 @@
 // brisk_shard -- the multi-GPU counting job from C++ (north_star: "host code stays C++"): one process per GPU, reads sharded
 // by index, super-k-mer records routed to the owner of their bucket range with ONE all-to-all over RCCL (counts first,
-// then the payload: grouped ncclSend/ncclRecv), insert purely local.  The Python twin of this flow is
+// then the payload -- records and the scan's per-partition counts in one group of ncclSend/ncclRecv), insert purely local.  The Python twin of this flow is
 // brisk_amd/exchange.py (torch.distributed); both sit on the same C-ABI calls: brisk_hip_scan_packed -> route_records ->
 // export_hist -> [exchange] -> insert_records_hist.  The reference is single-process: nothing here has a counterpart in it.
 //
@@ -177,6 +177,30 @@ struct Transport {
             }
         }
     }
+    // records AND histogram slices in one exchange step: with RCCL one group of sends and receives (to every peer its records and the
+    // slice of its partition range, from every peer mine), i.e. one launch on the wire where there used to be two collectives
+    void exchange_with_slices(const uint64_t* d_send, const std::vector<uint64_t>& send_counts, uint64_t* d_recv, const std::vector<uint64_t>& recv_counts, uint64_t words,
+                              const uint64_t* d_hist, const std::vector<uint64_t>& lens, uint64_t* d_slices, uint64_t my_len) {
+        if (!rccl) {
+            exchange(d_send, send_counts, d_recv, recv_counts, words);
+            exchange(d_hist, lens, d_slices, std::vector<uint64_t>(world, my_len), 1);
+            return;
+        }
+        step++;
+        NCCLOK(ncclGroupStart());
+        uint64_t so = 0, ro = 0, ho = 0;
+        for (int p = 0; p < world; p++) {
+            if (send_counts[p]) NCCLOK(ncclSend(d_send + so * words, send_counts[p] * words, ncclUint64, p, comm, stream));
+            if (recv_counts[p]) NCCLOK(ncclRecv(d_recv + ro * words, recv_counts[p] * words, ncclUint64, p, comm, stream));
+            if (lens[p]) NCCLOK(ncclSend(d_hist + ho, lens[p], ncclUint64, p, comm, stream));
+            if (my_len) NCCLOK(ncclRecv(d_slices + (uint64_t)p * my_len, my_len, ncclUint64, p, comm, stream));
+            so += send_counts[p];
+            ro += recv_counts[p];
+            ho += lens[p];
+        }
+        NCCLOK(ncclGroupEnd());
+        HIPOK(hipStreamSynchronize(stream));
+    }
     void barrier() {
         std::vector<uint64_t> one(world, 1);
         exchange_counts(one);
@@ -266,16 +290,15 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> send_counts(world), lens(world);
     BRISKOK(h, brisk_hip_route_records(h, d_rec, n_rec, d_out, send_counts.data()));
     BRISKOK(h, brisk_hip_export_hist(h, d_hist, lens.data()));
-    // the all-to-all: counts, then the records, then the histogram slices (every rank sends owner d the slice of d's range)
+    // the all-to-all: counts, then ONE payload exchange -- the records and the histogram slices (every rank sends owner d the slice of d's range)
     const std::vector<uint64_t> recv_counts = tp.exchange_counts(send_counts);
     uint64_t n_in = 0;
     for (uint64_t c : recv_counts) n_in += c;
     uint64_t *d_inbox, *d_slices;
     HIPOK(hipMalloc((void**)&d_inbox, (n_in + 1) * W * 8));
-    tp.exchange(d_out, send_counts, d_inbox, recv_counts, W);
     const uint64_t my_len = lens[rank];
     HIPOK(hipMalloc((void**)&d_slices, ((uint64_t)world * my_len + 1) * 8));
-    tp.exchange(d_hist, lens, d_slices, std::vector<uint64_t>(world, my_len), 1);
+    tp.exchange_with_slices(d_out, send_counts, d_inbox, recv_counts, W, d_hist, lens, d_slices, my_len);
     // insert what this rank owns
     BRISKOK(h, brisk_hip_insert_records_hist(h, d_inbox, n_in, d_slices, (uint32_t)world));
     BRISKOK(h, brisk_hip_sync(h));

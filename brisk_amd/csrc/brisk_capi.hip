@@ -89,6 +89,8 @@ struct brisk_hip_index {
     bool trace = false;         // BRISK_TRACE=1 at create: one stderr line per batch saying which host path and which insert kernel took it
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
     u32* d_ovf_cnt = nullptr;              // OVF_REGIONS counters of the binned scan's overflow area
+    std::vector<u64> owner_cut;            // sharded index: owner o holds partitions [owner_cut[o], owner_cut[o + 1]) (n_owners + 1 entries)
+    u32* d_owner_cut = nullptr;            // the same on the device once brisk_hip_set_owner_cuts has replaced the equal ranges (else null)
     unsigned long long* d_hist = nullptr;  // n_parts + 1
     u32* d_off = nullptr;                  // n_parts + 1
     u32* d_cur32 = nullptr;                // n_parts
@@ -416,11 +418,12 @@ struct PartRange {
     u64 lo, len;
 };
 // first partition of owner o's range: the smallest p with p * N >> part_bits == o
-static u64 owner_first_partition(const BriskParams& P, u32 o) { return (((u64)o << P.part_bits) + P.n_owners - 1) / P.n_owners; }
+static u64 equal_range_first(const BriskParams& P, u32 o) { return (((u64)o << P.part_bits) + P.n_owners - 1) / P.n_owners; }
+static u64 owner_first_partition(const brisk_hip_index* h, u32 o) { return h->owner_cut.empty() ? equal_range_first(h->P, o) : h->owner_cut[o]; }
 static PartRange own_partitions(const brisk_hip_index* h) {
     if (h->P.n_owners <= 1) return PartRange{0, h->n_parts};
-    const u64 lo = owner_first_partition(h->P, h->P.owner_rank);
-    return PartRange{lo, owner_first_partition(h->P, h->P.owner_rank + 1) - lo};
+    const u64 lo = owner_first_partition(h, h->P.owner_rank);
+    return PartRange{lo, owner_first_partition(h, h->P.owner_rank + 1) - lo};
 }
 // exclusive prefix of the histogram's record counts over the index's own partitions -> d_off, d_cur32 (d_off[lo + len] = total)
 int prefix_partitions(brisk_hip_index* h, u32 sub = 0) {  // sub: over the records beyond `sub` per partition
@@ -1384,6 +1387,7 @@ void free_all(brisk_hip_index* h) {
     fr(h->ix.slot_end);
     fr(h->d_hist);
     fr(h->d_ovf_cnt);
+    fr(h->d_owner_cut);
     fr(h->d_off);
     fr(h->d_cur32);
     fr(h->d_touched);
@@ -2049,7 +2053,7 @@ BRISK_API int brisk_hip_export_hist(brisk_hip_index* h, uint64_t* d_hist_out, ui
     if (!h->scan_hist_valid) return fail(h, BRISK_HIP_EINVAL, "export_hist: no histogram (brisk_hip_scan_packed on a sharded index must come right before)");
     HIPCHK(h, hipMemcpyAsync(d_hist_out, h->d_hist, h->n_parts * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h->P, o + 1) - owner_first_partition(h->P, o);
+    for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h, o + 1) - owner_first_partition(h, o);
     return BRISK_HIP_OK;
 }
 
@@ -2063,7 +2067,28 @@ BRISK_API int brisk_hip_export_hist_add(brisk_hip_index* h, uint64_t* d_hist_acc
                        (unsigned long long*)d_hist_acc);
     if (int lrc = launch_check(h, "k_add_u64")) return lrc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h->P, o + 1) - owner_first_partition(h->P, o);
+    for (u32 o = 0; o < h->P.n_owners; o++) partitions_per_owner[o] = owner_first_partition(h, o + 1) - owner_first_partition(h, o);
+    return BRISK_HIP_OK;
+}
+
+BRISK_API int brisk_hip_set_owner_cuts(brisk_hip_index* h, const uint64_t* first_partition) {
+    if (!h || !first_partition) return BRISK_HIP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    if (int frc = enter(h)) return frc;
+    const u32 no = h->P.n_owners;
+    if (no < 2) return fail(h, BRISK_HIP_EINVAL, "set_owner_cuts: not a sharded index");
+    if (first_partition[0] != 0 || first_partition[no] != h->n_parts) return fail(h, BRISK_HIP_EINVAL, "set_owner_cuts: the ranges must cover partitions [0, 2^part_bits)");
+    for (u32 o = 0; o < no; o++)
+        if (first_partition[o] > first_partition[o + 1]) return fail(h, BRISK_HIP_EINVAL, "set_owner_cuts: first partitions must ascend");
+    if (h->arena_used_host || h->nb_skmers) return fail(h, BRISK_HIP_EINVAL, "set_owner_cuts: the index holds entries of the old ranges (brisk_hip_clear first)");
+    std::vector<u32> c32(no + 1);
+    for (u32 o = 0; o <= no; o++) c32[o] = (u32)first_partition[o];
+    if (!h->d_owner_cut) HIPCHK(h, hipMalloc((void**)&h->d_owner_cut, (ROUTE_MAX_OWNERS + 1) * 4));
+    HIPCHK(h, hipMemcpyAsync(h->d_owner_cut, c32.data(), (no + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->owner_cut.assign(first_partition, first_partition + no + 1);
+    h->scan_hist_valid = false;
     return BRISK_HIP_OK;
 }
 
@@ -2075,7 +2100,7 @@ BRISK_API int brisk_hip_insert_records_hist(brisk_hip_index* h, const uint64_t* 
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     h->scan_hist_valid = false;
     if (!n_records) return BRISK_HIP_OK;
-    const u64 p_lo = owner_first_partition(h->P, h->P.owner_rank), len = owner_first_partition(h->P, h->P.owner_rank + 1) - p_lo;
+    const u64 p_lo = owner_first_partition(h, h->P.owner_rank), len = owner_first_partition(h, h->P.owner_rank + 1) - p_lo;
     HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (h->n_parts + 1) * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_small + 4, 0, 8, h->stream));
     hipLaunchKernelGGL(k_sum_slices, dim3(nblocks(len, 256)), dim3(256), 0, h->stream, (const unsigned long long*)d_hist_slices, n_slices, len, h->d_hist + p_lo,
@@ -2120,14 +2145,14 @@ static int route_impl(brisk_hip_index* h, const uint64_t* d_records, const uint3
     HIPCHK(h, hipMemsetAsync(d_ohist, 0, ((u64)no + 1) * 8, h->stream));
     {
         ProfScope ps(h, S_HIST);
-        hipLaunchKernelGGL(k_owner_hist, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_ohist);
+        hipLaunchKernelGGL(k_owner_hist, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_ohist, (const u32*)h->d_owner_cut);
         if (int lrc = launch_check(h, "k_owner_hist")) return lrc;
         hipLaunchKernelGGL(k_owner_offsets, dim3(1), dim3(ROUTE_MAX_OWNERS), 0, h->stream, no, grid, d_ohist, d_block, d_ooff);
         if (int lrc = launch_check(h, "k_owner_offsets")) return lrc;
     }
     {
         ProfScope ps(h, S_SCATTER);
-        hipLaunchKernelGGL(k_owner_scatter, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_out, d_tags, d_tags_out);
+        hipLaunchKernelGGL(k_owner_scatter, dim3(grid), dim3(256), 0, h->stream, h->P, d_records, n_records, chunk, d_block, d_out, d_tags, d_tags_out, (const u32*)h->d_owner_cut);
         if ((rc = launch_check(h, "k_owner_scatter"))) return rc;
     }
     std::vector<u32> off(no + 1);

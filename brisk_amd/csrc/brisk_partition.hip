@@ -208,11 +208,22 @@ __global__ void __launch_bounds__(256) k_need(const unsigned long long* __restri
 // records with LDS cursors seeded from those offsets (k_owner_scatter).
 #define ROUTE_BLOCKS 2048u
 #define ROUTE_MAX_OWNERS 256u
-__device__ __forceinline__ u32 owner_of_record(const BriskParams& P, u64 hdr) {
-    return (u32)(((u64)(hdr_bucket(hdr) >> P.shift) * P.n_owners) >> P.part_bits);
+// Owner of a record: the owners hold contiguous partition ranges.  cuts == null: equal ranges, owner = partition * N >> part_bits.
+// Else cuts[o] = first partition of owner o (cuts[0] = 0, n_owners + 1 entries, ascending): histogram-balanced ranges
+// (brisk_hip_set_owner_cuts; SURVEY.md 8(e): a partition is a range of hash values and minimizers are the SMALLEST hashes of
+// their windows, so equal ranges do not carry equal loads).
+__device__ __forceinline__ u32 owner_of_partition(const BriskParams& P, u32 part, const u32* __restrict__ cuts) {
+    if (!cuts) return (u32)(((u64)part * P.n_owners) >> P.part_bits);
+    u32 lo = 0, hi = P.n_owners;  // the owner o with cuts[o] <= part < cuts[o + 1]
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (cuts[mid] <= part) lo = mid; else hi = mid;
+    }
+    return lo;
 }
+__device__ __forceinline__ u32 owner_of_record(const BriskParams& P, u64 hdr, const u32* __restrict__ cuts) { return owner_of_partition(P, hdr_bucket(hdr) >> P.shift, cuts); }
 __global__ void __launch_bounds__(256) k_owner_hist(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u64 chunk, u32* __restrict__ block_cnt,
-                                                    unsigned long long* __restrict__ hist) {
+                                                    unsigned long long* __restrict__ hist, const u32* __restrict__ cuts) {
     __shared__ u32 s_cnt[ROUTE_MAX_OWNERS];
     __shared__ u32 s_inst[ROUTE_MAX_OWNERS];
     for (u32 o = threadIdx.x; o < P.n_owners; o += 256) s_cnt[o] = s_inst[o] = 0;
@@ -224,7 +235,7 @@ __global__ void __launch_bounds__(256) k_owner_hist(BriskParams P, const u64* __
         const bool ok = i < end;
         u64 hdr = 0;
         if (ok) hdr = rec[i * P.stride + P.nw];
-        const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+        const u32 owner = ok ? owner_of_record(P, hdr, cuts) : 0xffffffffu;
         unsigned long long todo = __ballot(ok);
         while (todo) {
             const int lead = __ffsll((long long)todo) - 1;
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(ROUTE_MAX_OWNERS) k_owner_offsets(u32 n_owners
 }
 __global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64* __restrict__ rec, u64 n_rec, u64 chunk,
                                                        const u32* __restrict__ block_off, u64* __restrict__ out,
-                                                       const u32* __restrict__ tag_in, u32* __restrict__ tag_out) {
+                                                       const u32* __restrict__ tag_in, u32* __restrict__ tag_out, const u32* __restrict__ cuts) {
     __shared__ u32 s_cur[ROUTE_MAX_OWNERS];
     for (u32 o = threadIdx.x; o < P.n_owners; o += 256) s_cur[o] = block_off[(u64)blockIdx.x * P.n_owners + o];
     __syncthreads();
@@ -274,7 +285,7 @@ __global__ void __launch_bounds__(256) k_owner_scatter(BriskParams P, const u64*
         const u64* src = rec + i * P.stride;
         u64 hdr = 0;
         if (ok) hdr = src[P.nw];
-        const u32 owner = ok ? owner_of_record(P, hdr) : 0xffffffffu;
+        const u32 owner = ok ? owner_of_record(P, hdr, cuts) : 0xffffffffu;
         unsigned long long todo = __ballot(ok);
         u32 slot = 0;
         while (todo) {
@@ -359,7 +370,7 @@ __global__ void __launch_bounds__(256) k_scatter(BriskParams P, const u64* __res
     const u64* src = rec + i * P.stride;
     const u64 hdr = src[P.nw];
     u32 bin = hdr_bucket(hdr) >> P.shift;
-    if (by_owner) bin = (u32)(((u64)bin * P.n_owners) >> P.part_bits);
+    if (by_owner) bin = owner_of_partition(P, bin, nullptr);
     const u32 slot = atomicAdd(&cursor[bin], 1u);
     if (slot >= n_rec) {  // histogram and records disagree: never write out of range
         atomicOr(err, 1u);

@@ -3,8 +3,12 @@
 One process per GPU.  Every rank scans its own reads; super-k-mer records are
 binned by the owner of their bucket range and exchanged with ONE all-to-all
 (counts first, then the payload) over torch.distributed -- backend "nccl" is RCCL
-over xGMI on ROCm, "gloo" on CPU for tests.  There is no other collective on the
-data path.  The reference is single-process; nothing here has a counterpart in it.
+over xGMI on ROCm, "gloo" on CPU for tests.  The scan's per-partition counts ride
+inside the same payload (behind the last piece's records), so a batch that goes in
+one piece is two collectives: the counts, the payload.  Ownership: equal partition
+ranges, or ranges balanced on the partition histogram of a first scan
+(balanced_cuts / ShardedCounter.balance).  The reference is single-process; nothing
+here has a counterpart in it.
 """
 from __future__ import annotations
 
@@ -25,6 +29,76 @@ def owner_of_bucket(rid, b: int, part_bits: int, n_owners: int, ext_bits: int = 
         raise ValueError("part_bits exceeds the routing id's 2b + ext_bits bits")
     part = rid >> shift
     return (part * n_owners) >> part_bits
+
+
+def uniform_cuts(part_bits: int, n_owners: int) -> List[int]:
+    """first partition of every owner (+ the end) under equal ranges: the smallest p with p * N >> part_bits == o"""
+    return [((o << part_bits) + n_owners - 1) // n_owners for o in range(n_owners)] + [1 << part_bits]
+
+
+def balanced_cuts(hist: torch.Tensor, part_bits: int, n_owners: int, coarse_bits: int = 14) -> List[int]:
+    """Cut points that give every owner the same share of the WORK in `hist` (a scan's partition histogram as export_hist
+    delivers it: records in the low, k-mer instances in the high 32 bits of each word; the insert's time follows the
+    instances).  Cuts fall on multiples of 2^(part_bits - coarse_bits) partitions: 2^coarse_bits block sums are all the
+    ranks have to agree on (ShardedCounter.balance all-reduces exactly those)."""
+    blocks = coarse_sums(hist, part_bits, coarse_bits)
+    return cuts_from_coarse(blocks, part_bits, n_owners, coarse_bits)
+
+
+def coarse_sums(hist: torch.Tensor, part_bits: int, coarse_bits: int = 14) -> torch.Tensor:
+    cb = min(coarse_bits, part_bits)
+    return (hist >> 32).reshape(1 << cb, -1).sum(dim=1)
+
+
+def cuts_from_coarse(blocks: torch.Tensor, part_bits: int, n_owners: int, coarse_bits: int = 14) -> List[int]:
+    cb = min(coarse_bits, part_bits)
+    cum = torch.cumsum(blocks.to(torch.float64), 0).cpu().numpy()
+    total = float(cum[-1]) if len(cum) else 0.0
+    if total <= 0:
+        return uniform_cuts(part_bits, n_owners)
+    cuts = [0]
+    for o in range(1, n_owners):
+        # the first block boundary at which the cumulated work reaches o / N of the total (closest boundary)
+        i = int(np.searchsorted(cum, total * o / n_owners))
+        if i + 1 < len(cum) and i >= 0 and abs(cum[i] - total * o / n_owners) < abs((cum[i - 1] if i else 0.0) - total * o / n_owners):
+            i += 1
+        cuts.append(max(cuts[-1], min(i, len(cum)) << (part_bits - cb)))
+    return cuts + [1 << part_bits]
+
+
+def owner_of_partition(part, cuts):
+    """owner of partition(s) `part` under cut points (first partition per owner + the end): ints or numpy arrays"""
+    return np.searchsorted(np.asarray(cuts[1:-1], dtype=np.int64), part, side="right")
+
+
+def pack_payload(out: torch.Tensor, counts, hist: torch.Tensor, lens, words: int, pay: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, List[int]]:
+    """One send buffer for records AND histogram slices: to owner d its counts[d] records (of `words` int64 each, `out` holds
+    them grouped by owner) followed by the lens[d] histogram words of d's partition range (`hist` is in partition order =
+    owner order).  Returns (buffer, words per destination)."""
+    send_words = [int(c) * words + int(l) for c, l in zip(counts, lens)]
+    total = sum(send_words)
+    if pay is None or pay.numel() < total:
+        pay = torch.empty(total + (total >> 3) + 64, dtype=out.dtype, device=out.device)
+    at = ro = ho = 0
+    for c, l in zip(counts, lens):
+        c, l = int(c), int(l)
+        pay[at: at + c * words].copy_(out[ro * words: (ro + c) * words])
+        pay[at + c * words: at + c * words + l].copy_(hist[ho: ho + l])
+        at, ro, ho = at + c * words + l, ro + c, ho + l
+    return pay, send_words
+
+
+def unpack_payload(stage: torch.Tensor, recv_counts, my_len: int, words: int, inbox: torch.Tensor, inbox_offset: int, slices: torch.Tensor) -> int:
+    """what pack_payload's buffers look like on arrival: from every source its records, then its slice of MY range.  Records go
+    to inbox[inbox_offset ...] back to back, slices side by side into `slices`; returns the records unpacked."""
+    at = n = 0
+    for s_, c in enumerate(recv_counts):
+        c = int(c)
+        inbox[(inbox_offset + n) * words: (inbox_offset + n + c) * words].copy_(stage[at: at + c * words])
+        slices[s_ * my_len: (s_ + 1) * my_len].copy_(stage[at + c * words: at + c * words + my_len])
+        at += c * words + my_len
+        n += c
+    return n
 
 
 def exchange_records(send: torch.Tensor, send_counts, words: int, group=None,
@@ -100,12 +174,12 @@ def return_sums(sums: torch.Tensor, recv_counts, send_counts, tags: torch.Tensor
 def agree_pieces(n_reads: int, device, group=None, four_from: int = 1 << 22) -> int:
     """The piece count of one ShardedCounter.count_packed call, the same on every rank: every piece issues the same
     all-to-alls on every rank, so the count follows the LARGEST share (one all-reduce(MAX)), not the local one.
-    Only the last piece's all-to-all is exposed: four pieces for a large batch, two for a small one."""
+    Only the last piece's all-to-all is exposed: four pieces for a large batch, one for a small one."""
     gloo = dist.get_backend(group) == "gloo"
     most = torch.tensor([int(n_reads)], dtype=torch.int64, device=torch.device("cpu") if gloo else device)
     dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
     most = int(most.item())
-    return 4 if most >= four_from else (2 if most >= 2 else 1)
+    return 4 if most >= four_from else 1  # (a small batch in one piece: two collectives, nothing to overlap them with)
 
 
 def suggest_part_bits(b: int, reads_per_batch: int) -> int:
@@ -134,7 +208,7 @@ class ShardedCounter:
         self.ix = brisk_amd.BriskHip(k, m, b, device=device, stream=stream.cuda_stream, owner_rank=rank, n_owners=world,
                                      part_bits=part_bits)
         self.W = self.ix.record_words
-        self._rec = self._out = self._inbox = self._hist = self._slices = None
+        self._rec = self._out = self._inbox = self._hist = self._slices = self._pay = self._stage = None
         self._cap = 0
 
     # reads per rank from which a batch goes in four pieces (patchable: the tests lower it)
@@ -147,7 +221,7 @@ class ShardedCounter:
 
         COLLECTIVE: every rank of the group must call this the same number of times.  Ranks may hold different
         numbers of reads (0 included: the last batch of a sharded FASTA): the piece count -- every piece issues the
-        same three all-to-alls on every rank -- is agreed on with one all-reduce(MAX) of n_reads, or given
+        same two all-to-alls (counts, payload) on every rank -- is agreed on with one all-reduce(MAX) of n_reads, or given
         explicitly (the same value on every rank) as `pieces`; a rank with fewer reads than pieces runs empty pieces."""
         ix, W = self.ix, self.W
         if self.world == 1:
@@ -193,10 +267,12 @@ class ShardedCounter:
                             a_[: b_.numel()].copy_(b_)
                         self._out = new_out
                 out = self._out[hi_]
-                counts = ix.route_records(self._rec.data_ptr(), n_rec, out.data_ptr())
+                counts = [int(c) for c in ix.route_records(self._rec.data_ptr(), n_rec, out.data_ptr())]
                 # the scan counted its records per partition: each owner gets the slice of its range and adds the
                 # slices up instead of counting the records it receives again (209 M random atomics per 50 M reads)
                 lens = [int(v) for v in ix.export_hist_add(self._hist.data_ptr())]
+                last = hi_ == len(halves) - 1
+                my_len = lens[self.rank]
                 recv_counts = exchange_counts(counts, self.dev, self.group)
                 n_in = sum(recv_counts)
                 if (n_in_total + n_in) * W > self._inbox.numel():  # skewed ownership: make room (what arrived is kept)
@@ -208,19 +284,65 @@ class ShardedCounter:
                     bigger = torch.empty((n_in_total + n_in) * W * 2, dtype=torch.int64, device=self.dev)
                     bigger[: n_in_total * W].copy_(self._inbox[: n_in_total * W])
                     self._inbox = bigger
-                works.append(exchange_payload_async(out, counts, recv_counts, W, self._inbox, n_in_total, self.group))
-                n_in_total += n_in
-            my_len = lens[self.rank]
-            if self._slices is None or self._slices.numel() != self.world * my_len:
-                self._slices = torch.empty(self.world * my_len, dtype=torch.int64, device=self.dev)
+                if not last:
+                    works.append(exchange_payload_async(out, counts, recv_counts, W, self._inbox, n_in_total, self.group))
+                    n_in_total += n_in
+                    continue
+                # The last piece's payload carries the histogram slices too -- to owner d: its records, then the slice of d's
+                # partition range (summed over this batch's pieces) -- so that a batch is one counts exchange and ONE payload
+                # exchange per piece, nothing else (the slices used to travel in a collective of their own).
+                self._pay, send_words = pack_payload(out, counts, self._hist, lens, W, self._pay)
+                recv_words = [c * W + my_len for c in recv_counts]
+                if self._stage is None or self._stage.numel() < sum(recv_words):
+                    self._stage = torch.empty(sum(recv_words) + (sum(recv_words) >> 3) + 64, dtype=torch.int64, device=self.dev)
+                self.stream.synchronize()  # (the packed buffer is complete before the collective reads it)
+                w_last = exchange_payload_async(self._pay, send_words, recv_words, 1, self._stage, 0, self.group)
+                if self._slices is None or self._slices.numel() != self.world * my_len:
+                    self._slices = torch.empty(self.world * my_len, dtype=torch.int64, device=self.dev)
+                for w in works + [w_last]:
+                    if w is not None:
+                        w.wait()
+                works = []
+                n_in_total += unpack_payload(self._stage, recv_counts, my_len, W, self._inbox, n_in_total, self._slices)
             slices, n_slices = self._slices, self.world
-            works.append(exchange_payload_async(self._hist, lens, [my_len] * self.world, 1, slices, 0, self.group))
             self._cap = cap
-            for w in works:
-                if w is not None:
-                    w.wait()
             self.stream.synchronize()
             ix.insert_records_hist(self._inbox.data_ptr(), n_in_total, slices.data_ptr(), n_slices)
+
+    def balance(self, d_packed: torch.Tensor, d_starts: torch.Tensor, n_reads: int, threshold: float = 1.3) -> Optional[List[int]]:
+        """Histogram-balanced ownership, from a scan of (a sample of) this rank's reads BEFORE anything is counted:
+        every rank's partition histogram is reduced to 2^14 block sums of k-mer instances, the sums are all-reduced (128 KB), and
+        if the most loaded owner under equal ranges carries more than `threshold` times the mean, every rank installs the same
+        balanced cut points (brisk_hip_set_owner_cuts).  COLLECTIVE.  Returns the cut points installed, or None (equal ranges kept)."""
+        ix, W = self.ix, self.W
+        if self.world == 1:
+            return None
+        pb = ix.layout["part_bits"]
+        with torch.cuda.stream(self.stream):
+            cap = max(ix.scan_bound(d_starts.data_ptr(), n_reads), 1)
+            rec = torch.empty(cap * W, dtype=torch.int64, device=self.dev)
+            hist = torch.empty(1 << pb, dtype=torch.int64, device=self.dev)
+            self.stream.synchronize()
+            ix.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), n_reads, rec.data_ptr(), cap)
+            ix.export_hist(hist.data_ptr())
+            blocks = coarse_sums(hist, pb).to(torch.int64)
+            del rec, hist
+        gloo = dist.get_backend(self.group) == "gloo"
+        red = blocks.cpu() if gloo else blocks
+        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=self.group)
+        blocks = red.to(torch.float64).cpu()
+        uni = uniform_cuts(pb, self.world)
+        cb = min(14, pb)
+        cum = torch.cat([torch.zeros(1, dtype=torch.float64), torch.cumsum(blocks, 0)])
+        load = lambda cuts: [float(cum[cuts[o + 1] >> (pb - cb)] - cum[cuts[o] >> (pb - cb)]) for o in range(self.world)]
+        total = float(cum[-1])
+        self.owner_load = {"uniform_max_over_mean": (max(load(uni)) * self.world / total) if total else 1.0}
+        if not total or self.owner_load["uniform_max_over_mean"] <= threshold:
+            return None
+        cuts = cuts_from_coarse(blocks, pb, self.world)
+        self.owner_load["balanced_max_over_mean"] = max(load(cuts)) * self.world / total
+        ix.set_owner_cuts(cuts)
+        return cuts
 
     def stats(self) -> dict:
         """Brisk::stats of the whole sharded index: buckets, super-k-mers, entries and memory add up over the

@@ -110,7 +110,7 @@ SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
     "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_reallocate", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
-    "brisk_hip_get_packed", "brisk_hip_insert_records", "brisk_hip_export_hist", "brisk_hip_export_hist_add", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
+    "brisk_hip_get_packed", "brisk_hip_insert_records", "brisk_hip_set_owner_cuts", "brisk_hip_export_hist", "brisk_hip_export_hist_add", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
 ]
@@ -149,6 +149,7 @@ def load() -> C.CDLL:
     L.brisk_hip_scan_bound.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.brisk_hip_route_records.argtypes = [vp, vp, u64, vp, _u64p]
     L.brisk_hip_insert_records.argtypes = [vp, vp, u64]
+    L.brisk_hip_set_owner_cuts.argtypes = [vp, _u64p]
     L.brisk_hip_export_hist.argtypes = [vp, vp, _u64p]
     L.brisk_hip_export_hist_add.argtypes = [vp, vp, _u64p]
     L.brisk_hip_insert_records_hist.argtypes = [vp, vp, u64, vp, u32]
@@ -347,6 +348,12 @@ class BriskHip:
 
     def insert_records(self, d_records: int, n: int):
         self._chk(self.L.brisk_hip_insert_records(self.h, d_records, n))
+
+    def set_owner_cuts(self, first_partition) -> None:
+        """owner o holds partitions [first_partition[o], first_partition[o + 1]); the same array on every rank, before anything is routed"""
+        cuts = np.ascontiguousarray(first_partition, np.uint64)
+        assert len(cuts) == self.layout["n_owners"] + 1
+        self._chk(self.L.brisk_hip_set_owner_cuts(self.h, cuts))
 
     def export_hist(self, d_hist_out: int) -> np.ndarray:
         """copy the last scan's per-partition histogram (2^part_bits u64) to d_hist_out; returns the slice length per owner"""

@@ -56,6 +56,7 @@
  *                               apps/counter.cpp:242-261) so that records can be
  *                               exchanged between GPUs (no reference counterpart:
  *                               the reference is single-process)
+ *   brisk_hip_set_owner_cuts    no reference counterpart: which partition range each GPU of a sharded job owns
  *   brisk_hip_export_hist / brisk_hip_export_hist_add / brisk_hip_insert_records_hist
  *                               no reference counterpart: the per-partition record counts of a scan travel with
  *                               the records so that the owner need not count them again
@@ -83,7 +84,7 @@
 extern "C" {
 #endif
 
-#define BRISK_HIP_ABI_VERSION 3
+#define BRISK_HIP_ABI_VERSION 4
 
 enum {
     BRISK_HIP_OK = 0,
@@ -237,6 +238,14 @@ int brisk_hip_export_hist(brisk_hip_index *h, uint64_t *d_hist_out, uint64_t *pa
 int brisk_hip_export_hist_add(brisk_hip_index *h, uint64_t *d_hist_acc, uint64_t *partitions_per_owner);
 int brisk_hip_insert_records_hist(brisk_hip_index *h, const uint64_t *d_records, uint64_t n_records,
                                   const uint64_t *d_hist_slices, uint32_t n_slices);
+/* Ownership of a sharded index (n_owners > 1): owner o holds the contiguous partition range [first_partition[o],
+ * first_partition[o + 1]) (HOST array of n_owners + 1 entries, first_partition[0] = 0, first_partition[n_owners] = 2^part_bits,
+ * ascending; an owner may hold nothing).  By default the ranges are equal (owner = partition * N >> part_bits).  Equal ranges do
+ * not carry equal loads -- a partition is a range of minimizer-hash values and minimizers are the smallest hashes of their
+ * windows ("histogram-balanced cut points if skew > 1.3x") -- so a job takes its cut points from the
+ * partition histogram of a first scan (export_hist, all ranks' histograms added up) and hands the SAME array to every rank
+ * before anything is routed or inserted: EINVAL on an index that holds entries.  No reference counterpart (single process). */
+int brisk_hip_set_owner_cuts(brisk_hip_index *h, const uint64_t *first_partition);
 /* The query path cut at the same boundary.  scan_query = the scan as query_sequence runs it (a read's
  * enumeration stops at the first super-k-mer after the first whose returned minimizer is 0,
  * apps/counter.cpp:304-306); d_tags[i] = index of the read record i came from.  route_tagged = route_records

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == sorted(hipapi.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.brisk_hip_abi_version() == 3
+    assert lib.brisk_hip_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_a_device(lib):

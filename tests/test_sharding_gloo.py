@@ -192,7 +192,110 @@ def test_piece_count_is_collective_with_unequal_shares():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0] == res[1] == [1, 1, 2, 2, 4, 4, 2]
+    assert res[0] == res[1] == [1, 1, 1, 1, 4, 4, 1]  # four pieces from the threshold up, else one (two collectives)
+
+
+def _balanced_worker(rank, world, port, k, m, b, part_bits, q):
+    """SURVEY.md 8(e) with histogram-balanced cut points and ONE payload collective: every rank builds its records and their
+    partition histogram (here: from the oracle's records, as the scan's export_hist delivers it), the ranks agree on cut points
+    from the all-reduced block sums, route by them, and exchange counts + one payload that carries records AND histogram slices"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from brisk_amd import exchange as X
+    O = oracle.Oracle()
+    reads = [bytes(r) for r in O.synth_reads(6000, 0, 600)]
+    mine = reads[rank::world]
+    h = O.index_new(k, m, b)
+    rec, W = _records_for(O, h, mine, k, m, b)
+    O.index_free(h)
+    shift = 2 * b - part_bits
+    hdr = rec[:, W - 1]
+    part = ((hdr & np.uint64(0xffffffff)) >> np.uint64(shift)).astype(np.int64)
+    n_k = ((hdr >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64)
+    hist = np.zeros(1 << part_bits, dtype=np.int64)
+    np.add.at(hist, part, 1 + (n_k << 32))
+    hist_t = torch.from_numpy(hist)
+    blocks = X.coarse_sums(hist_t, part_bits).to(torch.int64)
+    dist.all_reduce(blocks)  # 2^14 block sums: all the ranks have to agree on
+    cuts = X.cuts_from_coarse(blocks, part_bits, world)
+    uni = X.uniform_cuts(part_bits, world)
+    owner = X.owner_of_partition(part, cuts)
+    order = np.argsort(owner, kind="stable")
+    counts = np.bincount(owner, minlength=world)
+    lens = [cuts[o + 1] - cuts[o] for o in range(world)]
+    out = torch.from_numpy(rec[order].astype(np.int64).reshape(-1))
+    recv_counts = X.exchange_counts(counts, torch.device("cpu"))           # collective 1: the counts
+    pay, send_words = X.pack_payload(out, counts, hist_t, lens, W)
+    my_len = lens[rank]
+    recv_words = [c * W + my_len for c in recv_counts]
+    stage = torch.empty(max(sum(recv_words), 1), dtype=torch.int64)
+    wk = X.exchange_payload_async(pay, send_words, recv_words, 1, stage, 0)  # collective 2: records + histogram slices
+    if wk is not None:
+        wk.wait()
+    inbox = torch.empty(max(sum(recv_counts), 1) * W, dtype=torch.int64)
+    slices = torch.empty(world * my_len, dtype=torch.int64)
+    n_in = X.unpack_payload(stage, recv_counts, my_len, W, inbox, 0, slices)
+    got = inbox[: n_in * W].numpy().view(np.uint64).reshape(-1, W)
+    got_part = ((got[:, W - 1] & np.uint64(0xffffffff)) >> np.uint64(shift)).astype(np.int64)
+    # the slices, added up, are the histogram of what arrived (what brisk_hip_insert_records_hist relies on)
+    want_hist = np.zeros(my_len, dtype=np.int64)
+    np.add.at(want_hist, got_part - cuts[rank], 1 + (((got[:, W - 1] >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64) << 32))
+    slices_ok = bool((slices.reshape(world, my_len).sum(dim=0).numpy() == want_hist).all())
+    mine_ok = bool(((got_part >= cuts[rank]) & (got_part < cuts[rank + 1])).all())
+    inst = (blocks.to(torch.float64))
+    q.put((rank, cuts, uni, n_in, int(len(rec)), slices_ok, mine_ok, _expand(got, W, k, b)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,m,b,part_bits", [(31, 15, 14, 24), (63, 21, 14, 24)])
+def test_two_rank_balanced_cuts_and_single_payload(O, k, m, b, part_bits):
+    from collections import Counter
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_balanced_worker, args=(r, world, port, k, m, b, part_bits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1], "the ranks must install the same cut points"
+    cuts = res[0][1]
+    assert cuts[0] == 0 and cuts[-1] == 1 << part_bits and cuts == sorted(cuts)
+    assert all(x[5] and x[6] for x in res), "slices must add up to the received records' histogram, records must lie in the owner's range"
+    assert sum(x[3] for x in res) == sum(x[4] for x in res)
+    # balanced: the owners' shares of the k-mer instances are within a few percent of each other (equal ranges need not be:
+    # at k31 m15 a partition is the TOP bits of a hash whose minima the minimizers are)
+    loads = [sum(1 for _ in x[7]) for x in res]
+    assert max(loads) / (sum(loads) / world) < 1.06, loads
+    shards = [Counter(x[7]) for x in res]
+    assert not (set(shards[0]) & set(shards[1]))
+    total = shards[0] + shards[1]
+    reads = [bytes(r) for r in O.synth_reads(6000, 0, 600)]
+    lines, nk, nb = O.count(reads, k, m, b)
+    assert len(total) == nk and sorted(c % 256 for c in total.values()) == sorted(int(l.split()[2]) for l in lines)
+
+
+def test_cut_points_from_a_skewed_histogram():
+    from brisk_amd import exchange as X
+    pb = 16
+    w = torch.arange(1 << pb, dtype=torch.float64)
+    inst = ((1 << pb) - w).to(torch.int64)          # load falls linearly with the partition index: the first half holds 3/4 of it
+    hist = (inst << 32) | 1
+    for n in (2, 4, 8):
+        cuts = X.balanced_cuts(hist, pb, n)
+        loads = [int(inst[cuts[o]:cuts[o + 1]].sum()) for o in range(n)]
+        assert cuts[0] == 0 and cuts[-1] == 1 << pb and max(loads) / (sum(loads) / n) < 1.01
+        uni = X.uniform_cuts(pb, n)
+        assert max(int(inst[uni[o]:uni[o + 1]].sum()) for o in range(n)) / (sum(loads) / n) > 1.4
+    assert X.owner_of_partition(np.array([0, 9, 10, 99]), [0, 10, 50, 100]).tolist() == [0, 0, 1, 2]
+    assert X.uniform_cuts(4, 3) == [0, 6, 11, 16]  # the smallest p with p * 3 >> 4 == o
 
 
 def test_owner_of_bucket_takes_the_routing_id():

@@ -40,6 +40,7 @@ if "--one" in sys.argv:
     dev = torch.device("cuda", 0)
     d_packed = torch.zeros((reads * 150 + 15) // 16 + 4, dtype=torch.int32, device=dev)
     d_starts = torch.zeros(reads + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # torch fills on its own stream, the library works on another: the fill must have landed
     ix = brisk_amd.BriskHip(k, m, b)
     ix.synth_reads(max(reads * 10, 151), 0, reads, 150, d_packed.data_ptr(), d_starts.data_ptr())
     ix.sync()

@@ -8,6 +8,7 @@ G = n_reads * L // 15
 dev = torch.device("cuda", 0)
 d_packed = torch.zeros((n_reads * L + 15) // 16 + 4, dtype=torch.int32, device=dev)
 d_starts = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()  # torch fills on its own stream, the library works on another: the fill must have landed
 sums = torch.zeros(n_reads, dtype=torch.int64, device=dev)
 ix = brisk_amd.BriskHip(k, m, b)
 ix.synth_reads(G, 0, n_reads, L, d_packed.data_ptr(), d_starts.data_ptr())

@@ -24,6 +24,7 @@ dev = torch.device("cuda", 0)
 G = max(int(reads * 150 / 15), 151)
 d_packed = torch.zeros((reads * 150 + 15) // 16 + 4, dtype=torch.int32, device=dev)
 d_starts = torch.zeros(reads + 1, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()  # torch fills on its own stream, the library works on another: the fill must have landed
 ix = brisk_amd.BriskHip(k, m, b)
 ix.synth_reads(G, 0, reads, 150, d_packed.data_ptr(), d_starts.data_ptr())
 ix.sync()
