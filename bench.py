@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--part-bits", type=int, default=0, help="log2(#partitions); 0: library default")
     ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000, help="reads of the CPU baseline sample (10-15 s of the reference on the box's CPU share; the leg stops after ~30 s whatever the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end leg (N=1): the same synthetic reads written as .fa.gz and as plain FASTA, counted by "
+                                                                   "brisk_count from the file; 0: skip.  Reported under \"end_to_end\", never part of `value`")
     ap.add_argument("--get", action="store_true", help="also time the get path afterwards (N=1): per-read sums of counts over the same reads; reported under \"get\"")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
@@ -225,6 +227,11 @@ def main():
         line["verify"] = verify
         if get_leg:
             line["get"] = get_leg
+        if args.e2e_reads and N == 1:
+            try:
+                line["end_to_end"] = end_to_end(k, m, b, L, min(args.e2e_reads, n_reads), d_packed)
+            except Exception as e:  # noqa: BLE001  (the leg must never take the bench line with it)
+                line["end_to_end"] = {"error": repr(e)[:300]}
         print(json.dumps(line))
     if N > 1:
         dist.destroy_process_group()
@@ -319,6 +326,65 @@ def cpu_baseline(k, m, b, L, coverage, sample_reads):
         kind, used = "port", 1
     return {"value": round(nk / dt, 1), "unit": "k-mers/s", "cores": used, "kind": kind,
             "sample": "%d of %d synthetic %d bp reads, %gx coverage (genome %d bp): %d entries in %.2f s" % (done, sample_reads, L, coverage, G, nk, dt)}
+
+
+def end_to_end(k, m, b, L, n_reads, d_packed):
+    """From a file to the index, as the reference's app times it (apps/counter.cpp:375-381 includes the parsing): the first `n_reads`
+    of the bench's synthetic reads (unpacked from the device's 2-bit stream) written as FASTA -- gzipped and plain -- and counted by
+    brisk_amd/apps/brisk_count --bulk (C++: FastaBatcher -> brisk_hip_insert_reads -> index), which prints its stage split.  Stages
+    overlap (the reader works on batch i + 1 while batch i is counted; big batches are uploaded while the previous piece is
+    scanned), so they do not add up to the wall time.  Not `value`: the headline starts with the reads resident in HBM."""
+    import subprocess
+    import tempfile
+    import zlib
+    import numpy as np
+    import torch
+    import brisk_amd
+    exe = os.path.join(ROOT, "brisk_amd", "apps", "brisk_count")
+    if not os.path.exists(exe):
+        brisk_amd.build_apps()
+    dev = d_packed.device
+    tmp = tempfile.mkdtemp(prefix="brisk_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    fa, gz = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "reads.fa.gz")
+    t0 = time.perf_counter()
+    comp = zlib.compressobj(1, zlib.DEFLATED, 31)
+    lut = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=dev)  # A0 C1 T2 G3 (Kmers.cpp:442-444)
+    sh = torch.arange(30, -2, -2, device=dev, dtype=torch.int64)
+    with open(fa, "wb") as f_fa, open(gz, "wb") as f_gz:
+        step = 320_000  # reads per piece: a whole number of 16-nt words (320000 * 150 / 16)
+        for first in range(0, n_reads, step):
+            n = min(step, n_reads - first)
+            w0, w1 = first * L // 16, ((first + n) * L + 15) // 16
+            words = d_packed[w0:w1].to(torch.int64) & 0xffffffff
+            codes = ((words[:, None] >> sh[None, :]) & 3).reshape(-1)[first * L - w0 * 16: first * L - w0 * 16 + n * L]
+            reads = lut[codes].reshape(n, L).cpu().numpy()
+            rec = np.empty((n, L + 4), dtype=np.uint8)  # ">r\n" + read + "\n"
+            rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3:L + 3], rec[:, L + 3] = ord(">"), ord("r"), 10, reads, 10
+            blob = rec.tobytes()
+            f_fa.write(blob)
+            f_gz.write(comp.compress(blob))
+        f_gz.write(comp.flush())
+    t_files = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    out = {"reads": n_reads, "k": k, "m": m, "b": b, "cores": host_cpu_share(), "files_written_in_s": round(t_files, 1),
+           "bytes": {"fa": os.path.getsize(fa), "fa_gz": os.path.getsize(gz)},
+           "reference_app": "counter --mode 1 (parsing included): 0.909 M entries/s with 8 threads, 0.381 M with 1, k63 m21 b14, 1 M reads, survey container (BASELINE.md section 2)"}
+    for name, path in (("fa_gz", gz), ("fa", fa)):
+        best = None
+        for rep in range(2):  # (the first run pays the arena mapping and the page cache)
+            r = subprocess.run([exe, "--bulk", path, str(k), str(m), str(b), "-"], capture_output=True, text=True, timeout=900, env=dict(os.environ, BRISK_E2E_JSON="1"))
+            if r.returncode != 0:
+                raise RuntimeError("brisk_count failed: " + r.stderr[-300:])
+            d = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("E2E "))[4:])
+            if best is None or d["wall_s"] < best["wall_s"]:
+                best = d
+        best["entries_per_s"] = round(best["entries"] / best["wall_s"], 1)
+        best["input_MB_per_s"] = round(os.path.getsize(path) / best["wall_s"] / 1e6, 1)
+        out[name] = best
+    for f in (fa, gz):
+        os.remove(f)
+    os.rmdir(tmp)
+    return out
 
 
 def host_cpu_share():

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <atomic>
+#include <chrono>
 #include <iostream>
 #include <mutex>
 #include <string>
@@ -193,16 +194,49 @@ int main(int argc, char** argv) {
                 return 1;
             }
             // stream the file: a background thread inflates and segments batch i+1 while the GPU counts batch i
-            FastaBatcher batches(argv[2], batch_bases);
-            FastaBatch bt;
-            while (batches.next(bt)) {
-                rc = brisk_hip_insert_reads(h, bt.flat.data(), bt.offs.data(), bt.size());
-                if (rc != BRISK_HIP_OK) {
-                    std::cerr << brisk_hip_last_error(h) << std::endl;
-                    return 1;
+            const bool e2e = getenv("BRISK_E2E_JSON") != nullptr;  // bench.py's end-to-end leg: the stage split as one JSON line
+            if (e2e) brisk_hip_profile_enable(h, 1);
+            const auto t_start = std::chrono::steady_clock::now();
+            double insert_calls_s = 0.0;
+            uint64_t n_reads_in = 0, n_bases_in = 0, n_batches = 0;
+            {
+                FastaBatcher batches(argv[2], batch_bases);
+                FastaBatch bt;
+                while (batches.next(bt)) {
+                    const auto c0 = std::chrono::steady_clock::now();
+                    rc = brisk_hip_insert_reads(h, bt.flat.data(), bt.offs.data(), bt.size());
+                    insert_calls_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+                    if (rc != BRISK_HIP_OK) {
+                        std::cerr << brisk_hip_last_error(h) << std::endl;
+                        return 1;
+                    }
+                    n_reads_in += bt.size();
+                    n_bases_in += bt.flat.size();
+                    n_batches++;
+                }
+                const auto c0 = std::chrono::steady_clock::now();
+                brisk_hip_sync(h);  // (completes deferred inserts: the index is whole when the clock stops)
+                const double sync_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+                const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                brisk_hip_stats(h, &nb_buckets, &nb_skmers, &nb_kmers, &mem, &largest);
+                if (e2e) {
+                    uint32_t ns = 0;
+                    const char* names[BRISK_HIP_PROFILE_SLOTS];
+                    uint64_t launches[BRISK_HIP_PROFILE_SLOTS];
+                    double ms[BRISK_HIP_PROFILE_SLOTS];
+                    brisk_hip_profile_read(h, &ns, names, launches, ms);
+                    std::cout << "E2E {\"wall_s\": " << wall_s << ", \"reads\": " << n_reads_in << ", \"bases\": " << n_bases_in << ", \"batches\": " << n_batches
+                              << ", \"entries\": " << nb_kmers << ", \"reader_produce_s\": " << batches.produce_seconds() << ", \"main_waits_for_reader_s\": "
+                              << batches.consumer_wait_seconds() << ", \"insert_reads_calls_s\": " << insert_calls_s << ", \"final_sync_s\": " << sync_s << ", \"library_ms\": {";
+                    bool first = true;
+                    for (uint32_t i = 0; i < ns; i++)
+                        if (launches[i]) {
+                            std::cout << (first ? "" : ", ") << "\"" << names[i] << "\": " << ms[i];
+                            first = false;
+                        }
+                    std::cout << "}}" << std::endl;
                 }
             }
-            brisk_hip_stats(h, &nb_buckets, &nb_skmers, &nb_kmers, &mem, &largest);
             uint64_t cursor = 0, n = 0;
             const uint64_t cap = 1u << 20;
             std::vector<uint64_t> lo(cap), hi(cap);

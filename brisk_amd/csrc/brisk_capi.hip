@@ -21,9 +21,10 @@
 
 namespace {
 
-enum Slot { S_PACK, S_SYNTH, S_COUNT, S_SCAN, S_HIST, S_PSUM, S_TOUCHED, S_SCATTER, S_INSERT, S_QUERY, S_ENUM, S_LOOKUP, S_NSLOTS };
+enum Slot { S_PACK, S_SYNTH, S_COUNT, S_SCAN, S_HIST, S_PSUM, S_TOUCHED, S_SCATTER, S_INSERT, S_QUERY, S_ENUM, S_LOOKUP, S_UPLOAD, S_NSLOTS };
+// (the last slot is host wall time, not a kernel: a host batch's bytes from the caller's memory to the packed stream on the device)
 const char* const kSlotNames[S_NSLOTS] = {"k_pack_ascii", "k_synth", "k_count_kmers", "k_scan", "k_part_hist", "k_psum", "k_touched_need",
-                                          "k_scatter", "k_insert", "k_query", "k_enumerate", "k_lookup"};
+                                          "k_scatter", "k_insert", "k_query", "k_enumerate", "k_lookup", "host_upload_and_pack_wall"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -40,6 +41,7 @@ struct VmBuf {
     std::vector<size_t> sizes;
 };
 
+constexpr size_t kPinBytes = 8192;  // 255 k-mers x 22 bytes + the tail words of the per-call API's staging
 struct PendingEvent {
     int slot;
     hipEvent_t a, b;
@@ -88,6 +90,7 @@ struct brisk_hip_index {
     bool verify = false;        // BRISK_VERIFY=1 at create: every stage hand-over of the host paths is checked (verify_upload, verify_records)
     bool trace = false;         // BRISK_TRACE=1 at create: one stderr line per batch saying which host path and which insert kernel took it
     DevBuf staging, parted, desc, chunk_buf, tags_a, tags_b, packed_tmp, bases_tmp, starts_tmp, sums_tmp, enum_out, lookup_buf;
+    DevBuf packed_tmp2, starts_tmp2;  // the second set of insert_reads_pipelined: one sub-batch is scanned while the next one arrives
     u32* d_ovf_cnt = nullptr;              // OVF_REGIONS counters of the binned scan's overflow area
     std::vector<u64> owner_cut;            // sharded index: owner o holds partitions [owner_cut[o], owner_cut[o + 1]) (n_owners + 1 entries)
     u32* d_owner_cut = nullptr;            // the same on the device once brisk_hip_set_owner_cuts has replaced the equal ranges (else null)
@@ -99,6 +102,7 @@ struct brisk_hip_index {
     u32 n_scan_blocks = 0;
     unsigned long long* d_small = nullptr;  // [0] n_rec [1] overflow(u32) [2] n_touched(u32) [3] need [4] kmers bound
     unsigned long long* h_small = nullptr;  // pinned mirror
+    char* h_pin = nullptr;                  // pinned staging of the per-call API (one vector's k-mers in, ids out: one copy each way)
     u64 nb_skmers = 0;
     std::vector<u32> h_dir_cnt;  // enumeration snapshot
     bool dir_snapshot_valid = false;
@@ -1164,7 +1168,9 @@ std::mutex g_upload_mu;
 std::vector<UploadLane> g_upload;
 int g_upload_device = -1;
 
-int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, u64 n_words) {
+// `pipelined` (insert_reads_pipelined's uploader thread): the destination is free by the caller's bookkeeping and the handle's own
+// stream belongs to the caller's thread -- only the lanes' streams are touched here, and an error text goes to *err_out, not h->err.
+int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, u64 n_words, bool pipelined = false, std::string* err_out = nullptr) {
     const u64 n_chunks = (nb + kUploadChunk - 1) / kUploadChunk;
     auto in_one_piece = [&]() -> int {  // plain copy of the whole input, then one pack launch
         int rc;
@@ -1176,7 +1182,7 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
         }
         return launch_check(h, "k_pack_ascii");
     };
-    if (n_chunks < 4) return in_one_piece();  // small input: not worth the threads
+    if (n_chunks < 4 && !pipelined) return in_one_piece();  // small input: not worth the threads
     std::lock_guard<std::mutex> lk(g_upload_mu);
     if (g_upload_device != h->device) {  // first use on this device: the lanes stay for the life of the process
         for (UploadLane& l : g_upload)
@@ -1198,11 +1204,15 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
         }
         if (!ok) {  // no room for the pinned lanes (192 MiB of host, as much of device memory): the plain path still works
             (void)hipGetLastError();
+            if (pipelined) {
+                if (err_out) *err_out = "upload: no pinned lanes";
+                return BRISK_HIP_ENOMEM;
+            }
             return in_one_piece();
         }
         g_upload_device = h->device;
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // d_packed may still be read by earlier work of this index
+    if (!pipelined) HIPCHK(h, hipStreamSynchronize(h->stream));  // d_packed may still be read by earlier work of this index
     std::vector<hipError_t> err(kUploadLanes, hipSuccess);
     std::vector<std::thread> workers;
     for (unsigned t = 0; t < kUploadLanes; t++)
@@ -1226,7 +1236,13 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
         });
     for (std::thread& w : workers) w.join();
     for (hipError_t e : err)
-        if (e != hipSuccess) return fail(h, BRISK_HIP_EHIP, std::string("upload: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+            if (err_out) {
+                *err_out = std::string("upload: ") + hipGetErrorString(e);
+                return BRISK_HIP_EHIP;
+            }
+            return fail(h, BRISK_HIP_EHIP, std::string("upload: ") + hipGetErrorString(e));
+        }
     return BRISK_HIP_OK;
 }
 
@@ -1333,6 +1349,10 @@ int for_each_host_batch(brisk_hip_index* h, const char* bases, const uint64_t* o
         if ((rc = upload_and_pack(h, bases + offsets[r0], nb, (u32*)h->packed_tmp.p, n_words))) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->verify && (rc = verify_upload(h, bases + offsets[r0], nb, (const u32*)h->packed_tmp.p, n_words, "before the scan"))) return rc;
+        if (h->profiling) {
+            h->prof_ms[S_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count();
+            h->prof_launches[S_UPLOAD]++;
+        }
         if (dbg_up) fprintf(stderr, "[brisk_hip] upload: %llu bases in %.1f ms (offsets prepared in %.1f ms)\n", (unsigned long long)nb,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count(),
                             std::chrono::duration<double, std::milli>(t_a - t_0).count());
@@ -1342,6 +1362,83 @@ int for_each_host_batch(brisk_hip_index* h, const char* bases, const uint64_t* o
             if ((rc = verify_upload(h, bases + offsets[r0], nb, (const u32*)h->packed_tmp.p, n_words, "after the scan"))) return rc;
         }
         r0 = r1;
+    }
+    return BRISK_HIP_OK;
+}
+
+// A big host batch in sub-batches of twelve upload chunks (192 MiB of ASCII, ~1.3 M reads of 150 bp): an uploader thread drives the
+// pinned lanes for sub-batch j + 1 while this thread scans sub-batch j (small scans are deferred inserts: their records collect
+// and go in together), two packed buffers taking turns.  Round 2 uploaded a whole call's bytes, then computed: 10 M reads took
+// 30-32 ms of upload + 17 ms of scan and insert; the upload alone is what the link allows.
+constexpr u64 kPipeChunks = 12;
+int insert_reads_pipelined(brisk_hip_index* h, const char* bases, const uint64_t* offsets, uint64_t n_reads) {
+    struct Sub {
+        u64 r0, r1;
+    };
+    std::vector<Sub> subs;
+    const u64 want = kPipeChunks * kUploadChunk;
+    for (u64 r0 = 0; r0 < n_reads;) {
+        u64 r1 = (u64)(std::upper_bound(offsets + r0, offsets + n_reads + 1, offsets[r0] + want) - offsets) - 1;
+        if (r1 <= r0) r1 = r0 + 1;
+        r1 = std::min<u64>(r1, r0 + h->max_batch_reads);
+        if (offsets[n_reads] - offsets[r1] < 4 * kUploadChunk && n_reads - r0 <= h->max_batch_reads) r1 = n_reads;  // (no small last piece: every piece takes the lanes)
+        subs.push_back(Sub{r0, r1});
+        r0 = r1;
+    }
+    u64 max_words = 0, max_reads = 0;
+    for (const Sub& sb : subs) {
+        max_words = std::max<u64>(max_words, (offsets[sb.r1] - offsets[sb.r0] + 15) / 16);
+        max_reads = std::max<u64>(max_reads, sb.r1 - sb.r0);
+    }
+    int rc;
+    DevBuf* pk[2] = {&h->packed_tmp, &h->packed_tmp2};
+    DevBuf* st[2] = {&h->starts_tmp, &h->starts_tmp2};
+    for (int i = 0; i < 2; i++) {
+        if ((rc = ensure(h, *pk[i], (max_words + 4) * 4))) return rc;
+        if ((rc = ensure(h, *st[i], (max_reads + 1) * 8))) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the buffers may still be read by earlier work of this index
+    int up_rc = BRISK_HIP_OK;
+    std::string up_err;
+    double up_ms = 0.0;
+    auto upload = [&](size_t j) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const Sub sb = subs[j];
+        const u64 nb = offsets[sb.r1] - offsets[sb.r0];
+        up_rc = hipSetDevice(h->device) == hipSuccess ? upload_and_pack(h, bases + offsets[sb.r0], nb, (u32*)pk[j & 1]->p, (nb + 15) / 16, true, &up_err) : BRISK_HIP_EHIP;
+        up_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    std::thread up(upload, (size_t)0);
+    for (size_t j = 0; j < subs.size(); j++) {
+        up.join();
+        if (up_rc) return fail(h, up_rc, up_err.empty() ? "upload failed" : up_err);
+        if (j + 1 < subs.size()) up = std::thread(upload, j + 1);  // ... while the device works on sub-batch j
+        const Sub sb = subs[j];
+        const u64 nr = sb.r1 - sb.r0, nb = offsets[sb.r1] - offsets[sb.r0], n_words = (nb + 15) / 16;
+        auto body = [&]() -> int {
+            HIPCHK(h, hipMemcpyAsync(st[j & 1]->p, offsets + sb.r0, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
+            if (offsets[sb.r0]) {
+                hipLaunchKernelGGL(k_rebase, dim3(nblocks(nr + 1, 256)), dim3(256), 0, h->stream, (u64*)st[j & 1]->p, nr + 1, (u64)offsets[sb.r0]);
+                if (int lrc = launch_check(h, "k_rebase")) return lrc;
+            }
+            HIPCHK(h, hipMemsetAsync((char*)pk[j & 1]->p + n_words * 4, 0, 16, h->stream));
+            int brc;
+            if (h->verify && (brc = verify_upload(h, bases + offsets[sb.r0], nb, (const u32*)pk[j & 1]->p, n_words, "before the scan (pipelined)"))) return brc;
+            if ((brc = insert_packed_impl(h, (const u32*)pk[j & 1]->p, (const u64*)st[j & 1]->p, nr))) return brc;
+            if (h->verify) {
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if ((brc = verify_upload(h, bases + offsets[sb.r0], nb, (const u32*)pk[j & 1]->p, n_words, "after the scan (pipelined)"))) return brc;
+            }
+            return BRISK_HIP_OK;
+        };
+        if ((rc = body())) {
+            if (up.joinable()) up.join();  // (the uploader reads the caller's memory: it must be done before the call returns)
+            return rc;
+        }
+    }
+    if (h->profiling) {
+        h->prof_ms[S_UPLOAD] += up_ms;
+        h->prof_launches[S_UPLOAD] += subs.size();
     }
     return BRISK_HIP_OK;
 }
@@ -1365,7 +1462,7 @@ void free_all(brisk_hip_index* h) {
     hipStreamSynchronize(h->stream);  // nothing of ours may be in flight when the arena is unmapped
     auto fr = [](void* p) { if (p) hipFree(p); };
     for (DevBuf* b : {&h->huge, &h->pend, &h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp, &h->enum_out,
-                      &h->lookup_buf})
+                      &h->lookup_buf, &h->packed_tmp2, &h->starts_tmp2})
         fr(b->p);
     fr(h->d_coef);
     fr(h->d_tabs);
@@ -1394,6 +1491,7 @@ void free_all(brisk_hip_index* h) {
     fr(h->d_block_sums);
     fr(h->d_small);
     if (h->h_small) hipHostFree(h->h_small);
+    if (h->h_pin) hipHostFree(h->h_pin);
     for (auto& pe : h->pending) {
         hipEventDestroy(pe.a);
         hipEventDestroy(pe.b);
@@ -1596,6 +1694,7 @@ BRISK_API int brisk_hip_create(brisk_hip_index** out, uint8_t k, uint8_t m, uint
         HIPCHK(h, hipMemsetAsync(h->d_id_counter, 0, 8, h->stream));
         HIPCHK(h, hipMalloc((void**)&h->d_small, 64));
         HIPCHK(h, hipHostMalloc((void**)&h->h_small, 64));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_pin, kPinBytes));
         HIPCHK(h, hipMemsetAsync(h->d_small, 0, 64, h->stream));
         {
             // reserve virtual ranges as large as the device's memory; physical pages follow demand
@@ -1718,6 +1817,8 @@ BRISK_API int brisk_hip_insert_reads(brisk_hip_index* h, const char* bases, cons
     if (h->entry_ids) return fail(h, BRISK_HIP_EINVAL, "bulk count on an entry-id index");
     HIPCHK(h, hipSetDevice(h->device));
     std::lock_guard<std::recursive_mutex> call_lock(h->call_mu);
+    static const bool no_pipe = getenv("BRISK_UPLOAD_PIPELINE") && atoi(getenv("BRISK_UPLOAD_PIPELINE")) == 0;  // A/B and tests
+    if (!no_pipe && n_reads && offsets[n_reads] - offsets[0] >= (kPipeChunks + 4) * kUploadChunk) return insert_reads_pipelined(h, bases, offsets, n_reads);
     return for_each_host_batch(h, bases, offsets, n_reads, [&](u64, u64 nr) {
         return insert_packed_impl(h, (const u32*)h->packed_tmp.p, (const u64*)h->starts_tmp.p, nr);
     });
@@ -1883,7 +1984,7 @@ BRISK_API int brisk_hip_stats(brisk_hip_index* h, uint64_t* nb_buckets, uint64_t
     if (memory_bytes) {
         u64 m = h->arena_cap * (8ull * h->ix.key_words + 1) + h->n_parts * 16 + (h->n_buckets + 7) / 8 + (h->n_parts + 1) * 20;
         for (const DevBuf* b : {&h->bins, &h->staging, &h->parted, &h->desc, &h->chunk_buf, &h->route_buf, &h->tags_a, &h->tags_b, &h->packed_tmp, &h->bases_tmp, &h->starts_tmp, &h->sums_tmp,
-                                &h->enum_out, &h->lookup_buf, &h->pend, &h->huge, &h->seq_buf})
+                                &h->enum_out, &h->lookup_buf, &h->pend, &h->huge, &h->seq_buf, &h->packed_tmp2, &h->starts_tmp2})
             m += b->bytes;
         *memory_bytes = m;
     }
@@ -2304,8 +2405,43 @@ BRISK_API int brisk_hip_upsert_kmers(brisk_hip_index* h, const uint64_t* kmer_lo
     u64 *d_lo, *d_hi;
     uint8_t *d_idx, *d_new;
     u32* d_ids;
-    if ((rc = upload_queries(h, kmer_lo, kmer_hi, minimizer_idx, n, &d_lo, &d_hi, &d_idx, &d_ids, &d_new))) return rc;
     u32 done = 0;
+    {
+        // One vector (a super-k-mer: <= k - m + 1 k-mers) per call is what Brisk::insert_superkmer brings (brisk/Brisk.hpp:123-147,
+        // apps/counter.cpp:242-270): the call's cost is its host round trips, so the k-mers go in with ONE copy from pinned memory
+        // and ids, flags, progress and the arena cursor come back with one (six pageable copies and two synchronisations before).
+        if ((rc = ensure(h, h->lookup_buf, n * 22 + 64))) return rc;
+        char* base = (char*)h->lookup_buf.p;
+        const size_t tail = (n * 22 + 7) / 8 * 8;  // [n_done u32, pad | cursor u64] behind the arrays
+        d_lo = (u64*)base;
+        d_hi = (u64*)(base + n * 8);
+        d_ids = (u32*)(base + n * 16);
+        d_idx = (uint8_t*)(base + n * 20);
+        d_new = d_idx + n;
+        memcpy(h->h_pin, kmer_lo, n * 8);
+        memcpy(h->h_pin + n * 8, kmer_hi, n * 8);
+        memcpy(h->h_pin + n * 20, minimizer_idx, n);
+        HIPCHK(h, hipMemcpyAsync(base, h->h_pin, n * 21, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_upsert, dim3(1), dim3(64), 0, h->stream, h->P, h->ix, d_lo, d_hi, d_idx, (u32)n, d_ids, d_new, h->d_id_counter, (u32*)(base + tail),
+                           (unsigned long long*)(base + tail + 8));
+        if ((rc = launch_check(h, "k_upsert"))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->h_pin + n * 16, base + n * 16, tail + 16 - n * 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const u32 step = *(const u32*)(h->h_pin + tail);
+        h->arena_used_host = *(const unsigned long long*)(h->h_pin + tail + 8);
+        if (step == n) {
+            memcpy(ids, h->h_pin + n * 16, n * 4);
+            memcpy(newly, h->h_pin + n * 21, n);
+            h->nb_skmers += 1;
+            h->dir_snapshot_valid = false;
+            return BRISK_HIP_OK;
+        }
+        // the arena filled up part-way through the vector: the general path below grows it and goes on behind the k-mers that are in
+        // (their ids and flags are where the general path's copy at the end finds them: same buffer, same layout)
+        done = step;
+        if ((rc = ensure_arena(h, h->arena_cap))) return rc;
+    }
+    if ((rc = upload_queries(h, kmer_lo, kmer_hi, minimizer_idx, n, &d_lo, &d_hi, &d_idx, &d_ids, &d_new))) return rc;
     while (done < n) {
         hipLaunchKernelGGL(k_upsert, dim3(1), dim3(64), 0, h->stream, h->P, h->ix, d_lo + done, d_hi + done, d_idx + done, (u32)(n - done),
                            d_ids + done, d_new + done, h->d_id_counter, (u32*)(h->d_small + 7));

@@ -506,7 +506,8 @@ __device__ __forceinline__ u128x key_of_kmer(const BriskParams& P, u128x km, u32
 // k-mers it handled) when the arena cannot hold a move; the host grows it and calls again.
 __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const u64* __restrict__ q_lo, const u64* __restrict__ q_hi,
                                                const uint8_t* __restrict__ q_idx, u32 n, u32* __restrict__ out_id, uint8_t* __restrict__ out_new,
-                                               unsigned long long* __restrict__ id_counter, u32* __restrict__ n_done) {
+                                               unsigned long long* __restrict__ id_counter, u32* __restrict__ n_done,
+                                               unsigned long long* __restrict__ cursor_out = nullptr) {
     const u32 lane = threadIdx.x;
     u32 done = 0;
     for (u32 qi = 0; qi < n; qi++) {
@@ -563,7 +564,10 @@ __global__ void __launch_bounds__(64) k_upsert(BriskParams P, IndexDev ix, const
         }
         done = qi + 1;
     }
-    if (lane == 0) *n_done = done;
+    if (lane == 0) {
+        *n_done = done;
+        if (cursor_out) *cursor_out = *ix.cursor;  // (this wave's own atomics on it are done: same lane, program order)
+    }
 }
 
 // records -> the k-mers of each vector, unhashed (what SuperKmerEnumerator::next hands out):

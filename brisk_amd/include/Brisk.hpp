@@ -33,6 +33,12 @@ class Brisk {
 
     // brisk/Brisk.hpp:64-69
     DATA* get(kmer_full& kmer) {
+        {
+            // The walk the reference's apps run -- next() for every entry, get() on what it returned (apps/counter.cpp:90-126) --
+            // needs no look-up: the enumeration brought the entry's id along, and ids are for life (entries are never removed).
+            std::lock_guard<std::mutex> g(call_mu_);
+            if (have_last_ && kmer.kmer_s == last_kmer_ && kmer.minimizer_idx == last_idx_) return slot(last_id_);
+        }
         std::vector<kmer_full> one(1, kmer);
         return find(one)[0];
     }
@@ -122,6 +128,10 @@ class Brisk {
         kmer.minimizer_idx = e_idx_[enum_pos_];
         kmer.compute_mini(params.m);
         kmer.interleaved.clear();
+        last_kmer_ = kmer.kmer_s;
+        last_idx_ = kmer.minimizer_idx;
+        last_id_ = e_ids_[enum_pos_];
+        have_last_ = true;
         enum_pos_++;
         return true;
     }
@@ -213,6 +223,7 @@ class Brisk {
         delete menu;
         menu = big.release();
         params = grown;
+        have_last_ = false;
         chunks_ = std::move(fresh_chunks);
         enum_cursor_ = 0;
         enum_pos_ = 0;
@@ -259,6 +270,10 @@ class Brisk {
     std::vector<uint32_t> ids_, e_ids_;
     uint64_t enum_cursor_;
     size_t enum_pos_;
+    kint last_kmer_ = 0;  // what next() returned last, with its entry id (get() right behind next())
+    uint8_t last_idx_ = 0;
+    uint32_t last_id_ = 0;
+    bool have_last_ = false;
 };
 
 #endif

@@ -18,6 +18,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -182,10 +183,16 @@ class FastaBatcher {
         if (worker_.joinable()) worker_.join();
         if (map_) munmap((void*)map_, map_len_);
     }
+    // seconds the worker spent producing batches (inflate + parse; the time it waited for its slot to be taken is not in it), and
+    // seconds next() made its caller wait for a batch
+    double produce_seconds() const { return produce_s_; }
+    double consumer_wait_seconds() const { return wait_s_; }
     // Moves the next batch into `out`; false when the file is exhausted.
     bool next(FastaBatch& out) {
+        const auto w0 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return ready_ || finished_; });
+        wait_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         if (!ready_) {
             if (!error_.empty()) throw std::runtime_error(error_);
             return false;
@@ -202,12 +209,14 @@ class FastaBatcher {
         try {
             FastaBatch b;  // buffers circulate: what next() swapped back into the slot is filled again (no fresh pages per batch)
             for (;;) {
+                const auto p0 = std::chrono::steady_clock::now();
                 b.clear();
                 if (b.flat.capacity() < batch_bases_) b.flat.reserve(batch_bases_ + (batch_bases_ >> 4) + (1 << 20));
                 // a batch may end inside a sequence only at the end of the file: keep reading until a run closes
                 bool more = reader_.fill(b, batch_bases_);
                 while (more && !reader_.done() && b.flat.size() > b.offs.back()) more = reader_.fill(b, b.flat.size() + (1 << 16));
                 if (b.flat.size() > b.offs.back()) b.offs.push_back(b.flat.size());
+                produce_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count();
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [this] { return !ready_ || stop_; });
                 if (stop_) return;
@@ -271,6 +280,7 @@ class FastaBatcher {
             std::vector<FastaBatch> part(n_threads_);
             FastaBatch b;
             while (pos < end) {
+                const auto p0 = std::chrono::steady_clock::now();
                 const size_t want = batch_bases_ + (batch_bases_ >> 4) + 1;
                 const char* stop = (size_t)(end - pos) <= want ? end : FastaReader::next_record(base, pos + want, end);
                 // cut points at record starts
@@ -303,6 +313,7 @@ class FastaBatcher {
                     });
                 for (auto& x : th) x.join();
                 pos = stop;
+                produce_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count();
                 if (!publish(b, pos >= end)) return;
                 b.clear();
             }
@@ -322,6 +333,7 @@ class FastaBatcher {
     const char* map_;
     size_t map_len_;
     FastaBatch slot_;
+    double produce_s_ = 0.0, wait_s_ = 0.0;
     bool ready_, finished_, stop_;
     std::string error_;
     std::mutex mu_;

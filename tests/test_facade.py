@@ -82,6 +82,21 @@ def test_reference_counter_cpp_runs_on_the_gpu_index():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "All counts are correct !" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
     assert re.search(r"nb kmers: 6,105", out.stdout) and re.search(r"^237 bucket used", out.stdout, re.M)
+    # the per-call route's throughput, as the app itself prints it (--mode 1: count only; one launch per super-k-mer, entry ids and
+    # DATA on the host: the plumbing-compatible route, the bulk calls are the fast one)
+    import time
+    t0 = time.perf_counter()
+    out = subprocess.run([exe, "-f", os.path.join(GOLDEN, "debug_test.fa"), "-k", "31", "-m", "11", "-b", "4", "-t", "1", "--mode", "1"],
+                         capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert re.search(r"nb kmers: 27,283", out.stdout), out.stdout[-1500:]
+    m_ = re.search(r"Kmer counted elapsed time: ([0-9.]+)s", out.stdout)
+    line = "counter_ref --mode 1 on debug_test.fa (k31 m11 b4, 27,283 entries, 2,285 super-k-mers): %s s counting (%s entries/s), %.2f s wall" % (
+        m_.group(1) if m_ else "?", ("%.0f" % (27283 / float(m_.group(1)))) if m_ and float(m_.group(1)) > 0 else "?", wall)
+    print(line)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "facade_throughput.txt"), "w").write(line + "\n")
 
 
 @pytest.mark.gpu
