@@ -324,8 +324,11 @@ def cpu_baseline(k, m, b, L, coverage, sample_reads):
         nk, _ = O.index_stats(h)
         O.index_free(h)
         kind, used = "port", 1
+    what = ("the reference's own Kmers.cpp / hashing.cpp / Decycling.cpp / buckets.hpp / SuperKmerLight.hpp under this repo's directory driver "
+            "(oracle/ref_harness.cpp, OpenMP over reads; NOT apps/counter --mode 1, which parses FASTA under one lock and runs 0.9 M entries/s on 8 vCPU, BASELINE.md): "
+            "a stronger baseline than the app; run-to-run spread on a shared host ~40 %") if kind == "reference" else "this repo's plain-C restatement (oracle/brisk_oracle.c), one thread"
     return {"value": round(nk / dt, 1), "unit": "k-mers/s", "cores": used, "kind": kind,
-            "sample": "%d of %d synthetic %d bp reads, %gx coverage (genome %d bp): %d entries in %.2f s" % (done, sample_reads, L, coverage, G, nk, dt)}
+            "sample": "%d of %d synthetic %d bp reads, %gx coverage (genome %d bp): %d entries in %.2f s; %s" % (done, sample_reads, L, coverage, G, nk, dt, what)}
 
 
 def end_to_end(k, m, b, L, n_reads, d_packed):

@@ -2081,6 +2081,12 @@ BRISK_API int brisk_hip_memory_info(brisk_hip_index* h, uint64_t out[4]) {
     return BRISK_HIP_OK;
 }
 
+BRISK_API int brisk_hip_insert_slack(brisk_hip_index* h, uint64_t* entries) {
+    if (!h || !entries) return BRISK_HIP_EINVAL;
+    *entries = (uint64_t)h->insert_waves * ARENA_CHUNK;  // what insert_records_once adds to a batch's need (ensure_arena)
+    return BRISK_HIP_OK;
+}
+
 BRISK_API int brisk_hip_checksum(brisk_hip_index* h, uint64_t out[3]) {
     if (!h || !out) return BRISK_HIP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));

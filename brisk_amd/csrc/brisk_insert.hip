@@ -614,8 +614,11 @@ __device__ __forceinline__ void insert_body(const BriskParams& PP, const RecSrc&
                 }
                 PHASE(1)
                 const u32 raw_inst = __shfl(x0, nrec - 1, 64);
+                // (a quarter full at most in instances, less in distinct keys: probe rounds are wave-wide -- every round costs all 64 lanes
+                // whoever is still probing -- so a sparser table is worth its clearing: 25.8 -> 25.0 ms per 50 M reads against half full.
+                // Skipping, by a scalar branch, the instance slots nobody is pending in lost: 28.7 ms -- seven more spilled registers)
                 u32 tsize = 128;
-                while (tsize < 2 * ninst && tsize < TABLE) tsize <<= 1;
+                while (tsize < 4 * ninst && tsize < TABLE) tsize <<= 1;
                 if (!NW) {  // (compile-time geometry: the prefix travels in the records' info words, and the table -- which lies
                             // over the records there -- is cleared once the keys have been built from them)
                     s_pref[lane + 1] = x;

@@ -109,7 +109,7 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 SYMBOLS = [
     "brisk_hip_abi_version", "brisk_hip_create", "brisk_hip_destroy", "brisk_hip_clear", "brisk_hip_last_error", "brisk_hip_sync",
     "brisk_hip_get_layout", "brisk_hip_insert_reads", "brisk_hip_insert_packed", "brisk_hip_get_reads", "brisk_hip_lookup",
-    "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_reallocate", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
+    "brisk_hip_enumerate", "brisk_hip_stats", "brisk_hip_memory_info", "brisk_hip_insert_slack", "brisk_hip_reallocate", "brisk_hip_checksum", "brisk_hip_scan_packed", "brisk_hip_scan_bound", "brisk_hip_route_records",
     "brisk_hip_get_packed", "brisk_hip_insert_records", "brisk_hip_set_owner_cuts", "brisk_hip_export_hist", "brisk_hip_export_hist_add", "brisk_hip_insert_records_hist", "brisk_hip_scan_query", "brisk_hip_route_tagged", "brisk_hip_query_records", "brisk_hip_pack_ascii", "brisk_hip_synth_reads", "brisk_hip_debug_order_keys", "brisk_hip_scan_sequence", "brisk_hip_upsert_kmers", "brisk_hip_find_kmers",
     "brisk_hip_enumerate_ids", "brisk_hip_profile_enable",
     "brisk_hip_profile_read", "brisk_hip_profile_reset",
@@ -144,6 +144,7 @@ def load() -> C.CDLL:
     L.brisk_hip_stats.argtypes = [vp] + [C.POINTER(u64)] * 5
     L.brisk_hip_checksum.argtypes = [vp, _u64p]
     L.brisk_hip_memory_info.argtypes = [vp, _u64p]
+    L.brisk_hip_insert_slack.argtypes = [vp, C.POINTER(u64)]
     L.brisk_hip_reallocate.argtypes = [vp, vp]
     L.brisk_hip_scan_packed.argtypes = [vp, vp, vp, u64, vp, u64, C.POINTER(u64)]
     L.brisk_hip_scan_bound.argtypes = [vp, vp, u64, C.POINTER(u64)]
@@ -307,6 +308,12 @@ class BriskHip:
         out = np.zeros(4, np.uint64)
         self._chk(self.L.brisk_hip_memory_info(self.h, out))
         return dict(zip(("arena_mapped", "arena_reserved", "pooled", "retired_va"), (int(v) for v in out)))
+
+    def insert_slack(self) -> int:
+        """arena entries the single-pass insert reserves beyond a batch's own need (resident insert waves x chunk entries)"""
+        v = C.c_uint64()
+        self._chk(self.L.brisk_hip_insert_slack(self.h, C.byref(v)))
+        return v.value
 
     def checksum(self) -> tuple:
         """(entries, sum of counts, order-independent digest) of the whole index"""

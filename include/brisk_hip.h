@@ -47,6 +47,7 @@
  *                               (brisk/Brisk.hpp:166-179, brisk/DenseMenuYo.hpp:476-521)
  *   brisk_hip_stats             Brisk::stats (brisk/Brisk.hpp:194-197,
  *                               brisk/DenseMenuYo.hpp:545-568)
+ *   brisk_hip_memory_info / brisk_hip_insert_slack   no reference counterpart (Brisk::stats reports the process' peak RSS): the arena's bookkeeping
  *   brisk_hip_checksum          the next()+get() walk of verif_counts (apps/counter.cpp:90-126), reduced
  *                               to a digest on the device
  *   brisk_hip_scan_packed / brisk_hip_route_records / brisk_hip_insert_records
@@ -203,6 +204,10 @@ int brisk_hip_reallocate(brisk_hip_index *from, brisk_hip_index *to);
  * indexes (handed to the next index, given back when an allocation fails for lack of memory), out[3] = address space,
  * process-wide, that retired arenas keep reserved for the life of the process (no memory behind it). */
 int brisk_hip_memory_info(brisk_hip_index *h, uint64_t out[4]);
+/* Entries of arena the single-pass insert sets aside beyond a batch's own need ("every k-mer instance is new"): one partly used
+ * private chunk per persistent insert wave (resident waves x chunk entries).  A batch's insert needs room for
+ * instances + instances / 7 + this many entries, or it is split in halves (BRISK_HIP_ENOMEM when even one read does not fit). */
+int brisk_hip_insert_slack(brisk_hip_index *h, uint64_t *entries);
 
 /* Order-independent digest of the whole index, for parity checks at sizes where the multiset
  * cannot be compared line by line: out[0] = number of entries, out[1] = sum of counts,

@@ -789,7 +789,9 @@ def test_batch_splits_when_the_arena_reserve_does_not_fit(B, O, monkeypatch):
     want = O.count(reads, k, m, b)
     inst = sum(len(r) - k + 1 for r in reads)
     monkeypatch.delenv("BRISK_NO_VMM", raising=False)  # this test sets it itself, further down
-    slack = 5120 * 16384  # resident insert waves (20 per CU x 256 CUs) x ARENA_CHUNK of csrc/brisk_insert.hip: one partly used private chunk per persistent wave
+    with B.BriskHip(k, m, b) as probe:
+        slack = probe.insert_slack()  # resident insert waves x ARENA_CHUNK, from the library (was a constant copied from csrc/brisk_insert.hip by hand)
+    assert slack > 0
     monkeypatch.setenv("BRISK_ARENA_LIMIT", str(slack + inst // 2))  # the slack plus half the pessimistic bound
     assert gpu_count(B, reads, k, m, b) == want
     monkeypatch.setenv("BRISK_ARENA_LIMIT", "1000")  # nothing fits: a clean error, not a crash
