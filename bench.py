@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 # algorithmic HBM bytes per read = packed read in + each super-k-mer
 # record written once and read once + one count read-modify-write per k-mer instance
 B_ALG = {(63, 21, 14): 456.0, (31, 11, 11): 633.0}
+# super-k-mers per 150 bp read of the bench's synthetic reads (measured: records of the scan / reads), for the other parameter sets
+N_SKM = {(63, 21): 4.17, (31, 11): 11.1, (31, 15): 13.0}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -202,7 +204,7 @@ def main():
             launches_per_step = hot[dom]["launches"] / args.steps
             reads_per_launch = n_reads / launches_per_step  # rank 0's share (all shares are equal to within one read)
             avg_ms = hot[dom]["ms"] / hot[dom]["launches"]
-            n_skm = 4.17 if (k, m) == (63, 21) else 11.1
+            n_skm = N_SKM.get((k, m), 2.0 * max(L - k + 1, 0) / (k - m + 2))
             bytes_per_launch = b_alg(k, m, b, L, n_skm) * reads_per_launch
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -10,7 +10,7 @@ mkdir -p $OUT
 python3 /root/repo/tools/src_hash.py > $OUT/src.sha256   # the kernel sources these counters belong to
 echo "$ARGS" > $OUT/args.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline $ARGS > $OUT/bench_under_trace.json 2> $OUT/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > /dev/null 2> $OUT/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --e2e-reads 0 $ARGS > $OUT/bench_under_trace.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --e2e-reads 0 $ARGS > /dev/null 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --e2e-reads 0 $ARGS > /dev/null 2> $OUT/write.err
 echo collected $OUT
