@@ -255,18 +255,82 @@ int main(int argc, char** argv) {
     tp.stream = stream;
     tp.init();
 
-    // this rank's contiguous share of the job's reads, generated on its device
+    // this rank's contiguous share of the job's reads, generated on its device (below); ownership first
     const uint64_t first = total * (uint64_t)rank / (uint64_t)world, n_reads = total * (uint64_t)(rank + 1) / (uint64_t)world - first;
     const uint64_t genome = std::max<uint64_t>((uint64_t)(total * (double)L / coverage), L + 1);
     uint32_t* d_packed;
     uint64_t* d_starts;
+    // (the fills go on the index's stream: a fill on the null stream is not ordered with a non-blocking stream, and one that lands
+    // behind brisk_hip_synth_reads leaves a rank with reads of length zero -- seen as an intermittent short count in round 3's tests)
     HIPOK(hipMalloc((void**)&d_packed, ((n_reads * L + 15) / 16 + 4) * 4));
-    HIPOK(hipMemset(d_packed, 0, ((n_reads * L + 15) / 16 + 4) * 4));
+    HIPOK(hipMemsetAsync(d_packed, 0, ((n_reads * L + 15) / 16 + 4) * 4, stream));
     HIPOK(hipMalloc((void**)&d_starts, (n_reads + 1) * 8));
-    HIPOK(hipMemset(d_starts, 0, (n_reads + 1) * 8));
+    HIPOK(hipMemsetAsync(d_starts, 0, (n_reads + 1) * 8, stream));
+    HIPOK(hipStreamSynchronize(stream));
     if (n_reads) BRISKOK(h, brisk_hip_synth_reads(h, genome, first, n_reads, L, 1, 2, d_packed, d_starts));
     BRISKOK(h, brisk_hip_sync(h));
     tp.barrier();
+
+    // Ownership: equal partition ranges, unless a scan of this rank's first reads shows the most loaded owner more
+    // than 1.3x above the mean: then every rank installs the same histogram-balanced cut points (brisk_hip_set_owner_cuts; the twin of
+    // brisk_amd/exchange.py: ShardedCounter.balance).  2^14 block sums of k-mer instances per rank are all the ranks exchange.
+    // BRISK_SHARD_BALANCE=0 keeps equal ranges.  Once per job, before the clock starts.
+    if (world > 1 && !(getenv("BRISK_SHARD_BALANCE") && atoi(getenv("BRISK_SHARD_BALANCE")) == 0)) {
+        const uint32_t cb = std::min<uint32_t>(14, lay.part_bits);
+        const uint64_t nblk = 1ull << cb, per = n_parts >> cb;
+        const uint64_t sample = std::min<uint64_t>(n_reads, 2000000);
+        std::vector<uint64_t> mine(nblk, 0);
+        if (sample) {
+            uint64_t cap_s = 0, n_s = 0;
+            BRISKOK(h, brisk_hip_scan_bound(h, d_starts, sample, &cap_s));
+            uint64_t *d_r, *d_h;
+            HIPOK(hipMalloc((void**)&d_r, (cap_s + 1) * W * 8));
+            HIPOK(hipMalloc((void**)&d_h, n_parts * 8));
+            BRISKOK(h, brisk_hip_scan_packed(h, d_packed, d_starts, sample, d_r, cap_s, &n_s));
+            std::vector<uint64_t> ignore(world);
+            BRISKOK(h, brisk_hip_export_hist(h, d_h, ignore.data()));
+            std::vector<uint64_t> hh(n_parts);
+            HIPOK(hipMemcpy(hh.data(), d_h, n_parts * 8, hipMemcpyDeviceToHost));
+            for (uint64_t p = 0; p < n_parts; p++) mine[p / per] += hh[p] >> 32;
+            HIPOK(hipFree(d_r));
+            HIPOK(hipFree(d_h));
+        }
+        // all-gather of the block sums through the exchange step, then the same arithmetic on every rank
+        uint64_t *d_m, *d_all;
+        HIPOK(hipMalloc((void**)&d_m, (uint64_t)world * nblk * 8));
+        HIPOK(hipMalloc((void**)&d_all, (uint64_t)world * nblk * 8));
+        for (int p = 0; p < world; p++) HIPOK(hipMemcpy(d_m + (uint64_t)p * nblk, mine.data(), nblk * 8, hipMemcpyHostToDevice));
+        tp.exchange(d_m, std::vector<uint64_t>(world, nblk), d_all, std::vector<uint64_t>(world, nblk), 1);
+        std::vector<uint64_t> all((uint64_t)world * nblk);
+        HIPOK(hipMemcpy(all.data(), d_all, all.size() * 8, hipMemcpyDeviceToHost));
+        HIPOK(hipFree(d_m));
+        HIPOK(hipFree(d_all));
+        std::vector<double> cum(nblk + 1, 0.0);
+        for (uint64_t i = 0; i < nblk; i++) {
+            double v = 0;
+            for (int p = 0; p < world; p++) v += (double)all[(uint64_t)p * nblk + i];
+            cum[i + 1] = cum[i] + v;
+        }
+        const double tot = cum[nblk];
+        double worst = 0;
+        for (int o = 0; o < world; o++) {  // equal ranges: the smallest p with p * N >> part_bits == o
+            const uint64_t lo = (((uint64_t)o << lay.part_bits) + world - 1) / world, hi = (((uint64_t)(o + 1) << lay.part_bits) + world - 1) / world;
+            worst = std::max(worst, cum[hi / per] - cum[lo / per]);
+        }
+        if (tot > 0 && worst * world / tot > 1.3) {
+            std::vector<uint64_t> cuts(world + 1, 0);
+            for (int o = 1; o < world; o++) {
+                const double want = tot * o / world;
+                uint64_t i = (uint64_t)(std::lower_bound(cum.begin() + 1, cum.end(), want) - cum.begin());  // cum[i] >= want
+                if (i > 1 && std::fabs(cum[i - 1] - want) <= std::fabs(cum[std::min<uint64_t>(i, nblk)] - want)) i--;
+                cuts[o] = std::max<uint64_t>(cuts[o - 1], std::min<uint64_t>(i, nblk) * per);
+            }
+            cuts[world] = n_parts;
+            BRISKOK(h, brisk_hip_set_owner_cuts(h, cuts.data()));
+            if (rank == 0) std::cerr << "brisk_shard: equal ranges carry " << worst * world / tot << "x the mean: histogram-balanced cut points installed" << std::endl;
+        }
+        tp.barrier();
+    }
 
     const auto t0 = std::chrono::steady_clock::now();
     // scan -> records; route them by owner; the scan's per-partition histogram travels with them

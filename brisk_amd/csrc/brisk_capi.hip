@@ -821,6 +821,7 @@ int count_kmers(brisk_hip_index* h, const u64* d_starts, u64 n_reads, u64* out, 
     }
     HIPCHK(h, hipMemcpyAsync(h->h_small + 4, h->d_small + 4, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_small[5] >> 63) return fail(h, BRISK_HIP_EINVAL, "read offsets do not ascend (offsets[i + 1] < offsets[i]): not a read table, or the buffer was overwritten while the call ran");
     *out = h->h_small[4];
     if (out_long) *out_long = h->h_small[5];
     return BRISK_HIP_OK;

@@ -69,13 +69,17 @@ __global__ void __launch_bounds__(256) k_synth(u64 genome_len, u64 first_read, u
 }
 
 // out[0] = sum over reads of max(0, len-k+1): the number of k-mer instances (an upper bound on records);
-// out[1] = the share of it in reads of more than 1024 k-mers (a record every ~(w+2)/2 k-mers there, while a
+// out[1] = the share of it in reads of more than 1024 k-mers; its top bit: starts[] does not ascend (the host refuses the batch) (a record every ~(w+2)/2 k-mers there, while a
 // short read makes a few records whatever its length).  One atomic pair per block.
 __global__ void __launch_bounds__(256) k_count_kmers(const u64* __restrict__ starts, u64 n_reads, u32 k, unsigned long long* out) {
     __shared__ unsigned long long s_sum[4], s_long[4];
     unsigned long long acc = 0, lng = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
         const u64 len = starts[r + 1] - starts[r];
+        if (starts[r + 1] < starts[r]) {  // not a read table: a length that wraps would send the scan far outside the caller's buffer
+            atomicOr(out + 1, 1ull << 63);
+            continue;
+        }
         if (len >= k) {
             acc += len - k + 1;
             if (len - k + 1 > 1024) lng += len - k + 1;

@@ -352,6 +352,87 @@ def test_bucket_range_sharding_two_owners(B, O):
         assert (sorted(lines), nk, nb) == want
 
 
+def test_sharding_with_balanced_owner_cuts(B, O):
+    """brisk_hip_set_owner_cuts (histogram-balanced cut points): three owners whose ranges come from the partition
+    histogram of the whole job (k31 m15 b14: a partition is the top bits of the minimizer hash, equal ranges are lopsided), then the
+    same again with an owner that holds nothing.  Routed records lie in their owner's range, the slices add up, the union of the
+    shards is the oracle's index; cut points are refused on an index that holds entries."""
+    import torch
+    from brisk_amd import exchange as X
+    rng = random.Random(43)
+    reads = _random_reads(rng, 900, 8000) + SPECIAL
+    k, m, b, N = 31, 15, 14, 3
+    want = O.count(reads, k, m, b)
+    flat, offs = oracle.pack_reads(reads)
+    d_bases = torch.from_numpy(flat).cuda()
+    d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    d_starts = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    # the job's histogram, from an unsharded scan
+    with B.BriskHip(k, m, b) as one:
+        one.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        one.sync()
+        W, pb = one.record_words, one.layout["part_bits"]
+        bound = one.scan_bound(d_starts.data_ptr(), len(reads))
+        d_rec = torch.zeros(max(bound, 1) * W, dtype=torch.int64, device="cuda")
+        hist = torch.zeros(1 << pb, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        one.scan_packed(d_packed.data_ptr(), d_starts.data_ptr(), len(reads), d_rec.data_ptr(), bound)
+        one.export_hist(hist.data_ptr())
+        one.sync()
+    inst = (hist >> 32).to(torch.float64)
+    balanced = X.balanced_cuts(hist, pb, N)
+    uni = X.uniform_cuts(pb, N)
+    load = lambda cuts: [float(inst[cuts[o]:cuts[o + 1]].sum()) for o in range(N)]
+    assert max(load(balanced)) / (sum(load(balanced)) / N) < max(load(uni)) / (sum(load(uni)) / N)
+    for cuts in (balanced, [0, balanced[1], balanced[1], 1 << pb]):  # ... and owner 1 with an empty range
+        owners = [B.BriskHip(k, m, b, owner_rank=r, n_owners=N) for r in range(N)]
+        for ix in owners:
+            ix.set_owner_cuts(cuts)
+        inbox, slices = [[] for _ in range(N)], [[] for _ in range(N)]
+        share = [len(reads) * i // N for i in range(N + 1)]
+        for r in range(N):
+            ix = owners[r]
+            st = d_starts[share[r]:share[r + 1] + 1].contiguous()
+            n = share[r + 1] - share[r]
+            bound = ix.scan_bound(st.data_ptr(), n)
+            d_rec = torch.zeros(max(bound, 1) * W, dtype=torch.int64, device="cuda")
+            d_out = torch.zeros_like(d_rec)
+            d_hist = torch.zeros(1 << pb, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            n_rec = ix.scan_packed(d_packed.data_ptr(), st.data_ptr(), n, d_rec.data_ptr(), bound)
+            counts = [int(c) for c in ix.route_records(d_rec.data_ptr(), n_rec, d_out.data_ptr())]
+            lens = [int(v) for v in ix.export_hist(d_hist.data_ptr())]
+            ix.sync()
+            assert lens == [cuts[o + 1] - cuts[o] for o in range(N)] and sum(counts) == n_rec
+            at = 0
+            for o in range(N):
+                got = d_out[at * W:(at + counts[o]) * W].clone()
+                part = (got.reshape(-1, W)[:, W - 1] & 0xffffffff) >> (2 * b - pb)
+                assert bool(((part >= cuts[o]) & (part < cuts[o + 1])).all()), "a routed record lies outside its owner's range"
+                inbox[o].append(got)
+                slices[o].append(d_hist[cuts[o]:cuts[o + 1]].clone())
+                at += counts[o]
+        lines, nk, nb = [], 0, 0
+        for o in range(N):
+            recv = torch.cat(inbox[o]) if inbox[o] else torch.zeros(0, dtype=torch.int64, device="cuda")
+            sl = torch.cat(slices[o])
+            torch.cuda.synchronize()
+            if cuts[o + 1] > cuts[o]:
+                owners[o].insert_records_hist(recv.data_ptr() if recv.numel() else 0, recv.numel() // W, sl.data_ptr() if sl.numel() else 0, N)
+            else:
+                assert recv.numel() == 0
+            stt = owners[o].stats()
+            nk += stt["nb_kmers"]
+            nb += stt["nb_buckets"]
+            lines += oracle.multiset_lines(*owners[o].enumerate(), k)
+        assert (sorted(lines), nk, nb) == want
+        with pytest.raises(B.BriskHipError):  # the index holds entries of these ranges: new cut points are refused
+            owners[0].set_owner_cuts(uni)
+        for ix in owners:
+            ix.close()
+
+
 def test_sharding_with_more_partitions_and_summed_histograms(B, O):
     """A sharded job sized for N x the reads (include/brisk_hip.h, brisk_hip_options.part_bits): 2^25 and 2^27 partitions
     over 2 and 3 owners, each rank scanning its reads in two pieces whose histograms are summed before they travel
@@ -520,6 +601,30 @@ def test_parameter_contract(B):
     with pytest.raises(B.BriskHipError) as e:  # key does not fit 128 bits: outside this library's envelope
         B.BriskHip(63, 21, 1)
     assert e.value.code == 2
+
+
+def test_offsets_that_do_not_ascend_are_refused(B):
+    """A read table whose offsets go backwards (a caller's bug, or a buffer overwritten while the call runs: a fill on another
+    stream landing late did exactly that to this repo's own tools in round 3) must be refused before anything is scanned: a length
+    that wraps around would send the scan far outside the caller's buffer."""
+    import torch
+    reads = _random_reads(random.Random(3), 50, 2000)
+    flat, offs = oracle.pack_reads(reads)
+    d_bases = torch.from_numpy(flat).cuda()
+    d_packed = torch.zeros((len(flat) + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    bad = offs.astype(np.int64).copy()
+    bad[20] = 0  # offsets[20] < offsets[19]
+    d_starts = torch.from_numpy(bad).cuda()
+    torch.cuda.synchronize()
+    with B.BriskHip(31, 11, 4) as ix:
+        ix.pack_ascii(d_bases.data_ptr(), len(flat), d_packed.data_ptr())
+        ix.sync()
+        with pytest.raises(B.BriskHipError) as e:
+            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), len(reads))
+        assert e.value.code == 1 and "ascend" in str(e.value)
+        assert ix.stats()["nb_kmers"] == 0  # nothing was scanned, the handle stays usable
+        ix.insert_reads(reads)
+        assert ix.stats()["nb_kmers"] > 0
 
 
 def test_empty_inputs(B):

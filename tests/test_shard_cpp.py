@@ -57,3 +57,5 @@ def test_cpp_sharded_count_matches_one_index(tmp_path):
     assert _run_world(exe, 3, "files", total, k, m, b, tmp_path) == want    # three owners, shares of unequal size
     k, m, b, total = 31, 11, 11, 100_000                                    # config #2': routing ids == bucket ids, big partitions
     assert _run_world(exe, 2, "files", total, k, m, b, tmp_path) == _single_index(total, k, m, b)
+    k, m, b, total = 31, 15, 14, 300_000   # the reference's defaults: equal ranges are lopsided there, brisk_shard installs balanced cut points
+    assert _run_world(exe, 3, "files", total, k, m, b, tmp_path) == _single_index(total, k, m, b)
