@@ -129,3 +129,33 @@ def test_concurrent_insert_and_get_observe_whole_batches(tmp_path, O):
     O.index_free(h)
     assert finals[0] == want, "final get of batch 0's first reads differs from the oracle"
     print("mixed workload: %d batches, %d concurrent gets (%d of them saw later batches)" % (len(batches), len(gets), later))
+
+
+@pytest.mark.gpu
+def test_big_host_batch_is_uploaded_in_pieces_and_checked(monkeypatch, O):
+    """brisk_hip_insert_reads on more than 256 MiB of ASCII goes in sub-batches whose upload overlaps the previous piece's scan
+    (insert_reads_pipelined).  The same reads in calls of 100,000 (far below the threshold: one upload, then the scan) give the same
+    index (digest), with every stage hand-over checked (BRISK_VERIFY=1: the packed stream against the caller's bytes before and
+    after each piece's scan, the records against the k-mer count) -- and again, in a process of its own, with the pipeline off."""
+    import brisk_amd
+    k, m, b, n = 63, 21, 14, 2_000_000
+    G = n * L // 15
+    flat = np.ascontiguousarray(O.synth_reads(G, 0, n, L).reshape(-1))  # 300 MB of ASCII, the bench's generator
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    monkeypatch.setenv("BRISK_VERIFY", "1")
+    with brisk_amd.BriskHip(k, m, b) as ix:
+        step = 100_000
+        for i in range(0, n, step):
+            ix.insert_flat(flat[i * L:(i + step) * L], offs[:step + 1])
+        want = ix.checksum()
+    assert want[1] == n * (L - k + 1)
+    with brisk_amd.BriskHip(k, m, b) as ix:
+        ix.insert_flat(flat, offs)  # one call: 300 MB
+        assert ix.checksum() == want
+    # (BRISK_UPLOAD_PIPELINE is read once per process: the other setting runs in a process of its own)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import oracle, brisk_amd; O = oracle.Oracle(); n, L = %d, %d; "
+            "flat = np.ascontiguousarray(O.synth_reads(n * L // 15, 0, n, L).reshape(-1)); offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L); "
+            "ix = brisk_amd.BriskHip(%d, %d, %d); ix.insert_flat(flat, offs); print(ix.checksum())" % (ROOT, n, L, k, m, b))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, BRISK_UPLOAD_PIPELINE="0", BRISK_VERIFY="1"))
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.strip().splitlines()[-1] == str(want)
