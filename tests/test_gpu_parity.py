@@ -713,7 +713,8 @@ def test_chromosome_length_sequences_are_scanned_in_chunks(B, O):
     seqs += _random_reads(rng, 200, 3000)  # short reads in the same batch
     rc = lambda s: s[::-1].translate(str.maketrans("ACGT", "TGCA"))
     seqs.append(rc(seqs[0][1000:150_000]))
-    for k, m, b in ((63, 21, 14), (31, 11, 11), (31, 11, 4)):
+    # (31, 15, 14): the reference's defaults -- k <= 32, the window minimum comes from the per-lane queue, seeded chunks restart it
+    for k, m, b in ((63, 21, 14), (31, 11, 11), (31, 11, 4), (31, 15, 14), (29, 13, 9)):
         assert gpu_count(B, seqs, k, m, b) == O.count(seqs, k, m, b), (k, m, b)
     # the query path chunks long sequences too and stops each where query_sequence stops it (a returned minimizer of 0:
     # the poly-A stretches below), whatever chunk that falls in
