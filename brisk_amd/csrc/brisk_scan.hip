@@ -271,6 +271,8 @@ __device__ __forceinline__ void emit_record_wide(const BriskParams& P, const u32
 #ifdef SCAN_ATTR_NOATOMIC  // attribution builds: wrong results, timing only
             const u32 rank = (part * 7u + (threadIdx.x & 63)) % out.bin_cap;
 #else
+            // (Non-temporal record stores, to keep the histogram in the memory-side cache: 31-33 ms against 21.0 at k31 m15, 27.1 against
+            // 25.6 at k63.)
             // (Issuing all of a flush's atomics first -- a record's partition needs its minimizer only -- and building the records afterwards
             // was measured: 26.1 against 26.0 ms per 50 M reads at k63, 43.4 against 42.9 per 20 M at k31 m15.  What the records waited
             // for was not this atomic but the one behind the overflow area: ScanOut::ovf_cnt.)
@@ -280,9 +282,6 @@ __device__ __forceinline__ void emit_record_wide(const BriskParams& P, const u32
                 r = out.bins + ((u64)part * out.bin_cap + rank) * P.stride;
                 if (out.tag) out.tag[(u64)part * out.bin_cap + rank] = tag;  // query mode: the records' reads, laid out like the records
             } else {
-#ifdef SCAN_ATTR_NOOVF  // attribution builds: records beyond their bin are dropped
-                return;
-#endif
                 const u32 reg = part & (OVF_REGIONS - 1);
                 const u32 at = atomicAdd(&out.ovf_cnt[reg], 1u);
                 if (at >= out.ovf_region_cap) {
