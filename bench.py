@@ -119,7 +119,9 @@ def main():
     # one handle for the whole run: every step starts from brisk_hip_clear(), i.e. an
     # empty index whose device memory is already reserved (the allocator, not the path)
     from brisk_amd.exchange import ShardedCounter, suggest_part_bits
-    part_bits = args.part_bits or (suggest_part_bits(b, total_reads) if N > 1 else 0)
+    # partitions follow the batch (one batch per job here): at most 512 k-mer instances per partition (1024 with the two-word
+    # records of k <= 32, where fewer than 2^24 pay: exchange.suggest_part_bits); 2^24 for the headline config
+    part_bits = args.part_bits or suggest_part_bits(b, total_reads, L - k + 1, min_bits=22 if k <= 32 else 24, per_partition=1024 if k <= 32 else 512)
     sc = ShardedCounter(k, m, b, rank, N, dev_index, stream, part_bits=part_bits)
     ix = sc.ix
     # ownership (N > 1): equal partition ranges unless a scan of this rank's first reads shows the most loaded owner more than 1.3x

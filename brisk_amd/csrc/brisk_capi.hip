@@ -592,6 +592,8 @@ int insert_records_once(brisk_hip_index* h, const u64* d_rec, u64 n_rec, bool ha
         else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_INSERT_FAST(3, 49, 2)  // jobs of 2..8 x 50 M reads per batch over
         else if (!generic_only && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_INSERT_FAST(3, 49, 1)  // as many owners (brisk_hip_options.part_bits)
         else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_INSERT_FAST(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 5) LAUNCH_INSERT_FAST(2, 17, 5)  // (the same with 2^23 / 2^22 partitions: one batch of ~20 M reads,
+        else if (!generic_only && P.nw == 2 && P.kb == 17 && P.shift == 6) LAUNCH_INSERT_FAST(2, 17, 6)  // brisk_hip_part_bits_for_batch)
         else if (!generic_only && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_INSERT_FAST(2, 20, 0)  // k31 m11 b11
         else LAUNCH_INSERT(0, 0, 0)
 #undef LAUNCH_INSERT_FAST
@@ -864,7 +866,7 @@ int scan_to_staging(brisk_hip_index* h, const u32* d_packed, const u64* d_starts
 
 // the parameter sets k_insert_fast / k_query_fast are instantiated for (the only kernels that read the binned layout in query mode)
 static bool has_fast_geometry(const BriskParams& P) {
-    return (P.nw == 3 && P.kb == 49 && P.shift >= 1 && P.shift <= 4) || (P.nw == 2 && P.kb == 17 && P.shift == 4) || (P.nw == 2 && P.kb == 20 && P.shift == 0);
+    return (P.nw == 3 && P.kb == 49 && P.shift >= 1 && P.shift <= 4) || (P.nw == 2 && P.kb == 17 && P.shift >= 4 && P.shift <= 6) || (P.nw == 2 && P.kb == 20 && P.shift == 0);
 }
 
 // Scan a batch straight into per-partition bins (insert or query mode).  *applied = false: the batch does not qualify, or its
@@ -887,7 +889,8 @@ int scan_binned(brisk_hip_index* h, const u32* d_packed, const u64* d_starts, u6
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const u64 bytes = h->n_parts * cap * h->P.stride * 8;
-    if (forced <= 0 && (est < 2 * h->n_parts || cap > 64 || bytes > total_b / 4)) return BRISK_HIP_OK;  // sparse batch, big partitions, or too much memory
+    // (bins of up to 256 records: fewer, bigger partitions -- options.part_bits fitted to the batch -- keep the rank-is-the-slot layout)
+    if (forced <= 0 && (est < 2 * h->n_parts || cap > 256 || bytes > total_b / 4)) return BRISK_HIP_OK;  // sparse batch, big partitions, or too much memory
     if (h->n_parts * cap >= (1ull << 32)) return BRISK_HIP_OK;
     // (tests force tiny bins: most records lie beyond them, and the regions -- filled by the low bits of the partition -- are uneven when partitions are few)
     const u32 ovf_region_cap = (u32)(((forced > 0 ? 4 * est : est / 8) + 65536 + OVF_REGIONS - 1) / OVF_REGIONS);
@@ -1138,6 +1141,8 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
         else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 2) LAUNCH_QUERY_FAST(3, 49, 2)
         else if (fast && P.nw == 3 && P.kb == 49 && P.shift == 1) LAUNCH_QUERY_FAST(3, 49, 1)
         else if (fast && P.nw == 2 && P.kb == 17 && P.shift == 4) LAUNCH_QUERY_FAST(2, 17, 4)  // k31 m15 b14 (apps/counter.cpp:355)
+        else if (fast && P.nw == 2 && P.kb == 17 && P.shift == 5) LAUNCH_QUERY_FAST(2, 17, 5)
+        else if (fast && P.nw == 2 && P.kb == 17 && P.shift == 6) LAUNCH_QUERY_FAST(2, 17, 6)
         else if (fast && P.nw == 2 && P.kb == 20 && P.shift == 0) LAUNCH_QUERY_FAST(2, 20, 0)  // k31 m11 b11
         else if (bl) return fail(h, BRISK_HIP_EHIP, "binned query without a kernel for this geometry");
         else

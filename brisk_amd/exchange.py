@@ -182,17 +182,31 @@ def agree_pieces(n_reads: int, device, group=None, four_from: int = 1 << 22) -> 
     return 4 if most >= four_from else 1  # (a small batch in one piece: two collectives, nothing to overlap them with)
 
 
-def suggest_part_bits(b: int, reads_per_batch: int) -> int:
-    """log2(#partitions) for a sharded job whose ranks together count `reads_per_batch` reads per count_packed call
+def suggest_part_bits(b: int, reads_per_batch: int, kmers_per_read: int = 0, min_bits: int = 24, per_partition: int = 512) -> int:
+    """log2(#partitions) for a job that counts `reads_per_batch` reads per count_packed call, all ranks together
     (0: the library default, 2^24).  The insert wants 10-20 records per partition and call (include/brisk_hip.h,
     brisk_hip_options.part_bits): 50 M reads bring 209 M records, 12 per partition at 2^24.  N owners that each receive
     that much (N x 50 M reads per batch) keep the same density with N times the partitions -- each still walks only its
     own N-th of them; with 2^24 for 400 M reads the partitions hold 100 records each and the insert takes 2.5x as long
     (77 against 31 ms per owner and batch, tools/owner_emulation.py on one MI355X).  Explicit partition counts are bucket ranges:
-    at most 2b bits."""
+    at most 2b bits.
+    With `kmers_per_read` (read length - k + 1) the rule is stated in k-mer instances -- at most `per_partition` per partition
+    and call (512: the insert's chunk is 256 after its record-level dedupe) -- and also goes BELOW 2^24 for a batch that would
+    leave the default's partitions nearly empty: k31 m15 b14 brings 9 k-mers per record, and 20 M reads in 2^24 partitions
+    are 143 instances = 12 entries each; the same job takes 33.0 ms with 2^24, 29.3 with 2^23 and 26.1 with 2^22 partitions
+    (profiles/r03_part_bits_k31.txt: fewer histogram lines under the scan's atomics, which bound that scan, and fewer
+    partitions for the insert to walk; 2^21 doubles the insert).  k63 does not follow: its scan is bound by instruction
+    issue whatever the histogram's size and its insert loses 4.5 ms at 2^23, so 512 stays the default and bench.py passes
+    1024 for k <= 32 (two-word records, one-word keys).  For 150 bp reads at k = 63 both rules give the same numbers.
+    `min_bits` bounds the way down (default: never below 2^24): only 2^22 and 2^23 at k31 m15 b14 have specialised
+    insert/get kernels and measurements behind them, so bench.py passes 22 for k <= 32."""
     import math
-    if reads_per_batch <= 0:
+    if reads_per_batch <= 0 or 2 * b < 24:
         return 0
+    if kmers_per_read > 0:
+        bits = int(math.ceil(math.log2(max(reads_per_batch * kmers_per_read / float(per_partition), 1.0))))
+        bits = max(min(min_bits, 24), min(bits, 2 * b))
+        return 0 if bits == 24 else bits
     bits = min(int(round(math.log2(max(reads_per_batch, 3) / 3.0))), 2 * b)
     return bits if bits > 24 else 0
 

@@ -140,6 +140,47 @@ def test_hot_partition_multi_chunk(B, O):
         assert gpu_count(B, reads, k, m, b, part_bits=pb) == O.count(reads, k, m, b)
 
 
+def test_fewer_partitions_fitted_to_the_batch(B, O):
+    """k31 m15 b14 with 2^22 / 2^23 partitions (brisk_amd.exchange.suggest_part_bits with min_bits: what bench.py uses for
+    one batch of ~20 M reads): the specialised insert / get kernels of these geometries against the oracle on a small
+    read set (records through the staging path), and the bins of up to 256 records on a batch dense enough for the
+    binned layout (700 k reads: ~9 M records, more than two per partition) against the default 2^24 layout (bench.py's
+    own check covers the full size: every k-mer counted once, the digest of profiles/r03_part_bits_k31.txt)."""
+    import torch
+    rng = random.Random(2231)
+    k, m, b = 31, 15, 14
+    reads = _random_reads(rng, 1500, 9000) + SPECIAL
+    want = O.count(reads, k, m, b)
+    flat, offs = oracle.pack_reads(reads)
+    h = O.index_new(k, m, b)
+    O.index_insert_reads(h, flat, offs)
+    sums = O.index_query_reads(h, flat, offs)
+    O.index_free(h)
+    for pb in (22, 23):
+        assert gpu_count(B, reads, k, m, b, part_bits=pb) == want, pb
+        with B.BriskHip(k, m, b, part_bits=pb) as ix:
+            assert ix.layout["part_bits"] == pb
+            ix.insert_reads(reads)
+            assert np.array_equal(ix.get_reads(reads), sums), pb
+    n, L = 700_000, 150
+    d_packed = torch.zeros((n * L + 15) // 16 + 4, dtype=torch.int32, device="cuda")
+    d_starts = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    d_sums = {pb: torch.zeros(n, dtype=torch.int64, device="cuda") for pb in (0, 22, 23)}
+    torch.cuda.synchronize()
+    digest = {}
+    for pb in (0, 22, 23):
+        with B.BriskHip(k, m, b, part_bits=pb) as ix:
+            ix.synth_reads(n * L // 12, 0, n, L, d_packed.data_ptr(), d_starts.data_ptr())
+            ix.insert_packed(d_packed.data_ptr(), d_starts.data_ptr(), n)
+            ix.get_packed(d_packed.data_ptr(), d_starts.data_ptr(), n, d_sums[pb].data_ptr())
+            ix.sync()
+            st = ix.stats()
+            digest[pb] = (ix.checksum(), st["nb_kmers"], st["nb_buckets"])
+    assert digest[22] == digest[0] and digest[23] == digest[0], digest
+    assert digest[0][0][1] == n * (L - k + 1)
+    assert torch.equal(d_sums[22], d_sums[0]) and torch.equal(d_sums[23], d_sums[0])
+
+
 def test_lookup_and_get(B, O):
     rng = random.Random(21)
     reads = _random_reads(rng, 600, 6000) + SPECIAL

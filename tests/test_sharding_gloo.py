@@ -318,3 +318,13 @@ def test_partition_count_follows_the_batch():
     assert suggest_part_bits(14, 10**10) == 28         # bucket ranges: at most 2b bits
     assert suggest_part_bits(11, 400_000_000) == 0     # 2b = 22 < 24: nothing to scale
     assert suggest_part_bits(14, 0) == 0
+    # stated in k-mer instances (<= 512 per partition and call): the same answers at k63 / 150 bp ...
+    for reads, want in ((50_000_000, 0), (100_000_000, 25), (200_000_000, 26), (400_000_000, 27), (10**10, 28)):
+        assert suggest_part_bits(14, reads, 88) == want
+    # ... and fewer partitions than the default only where the caller allows it (k31 m15 b14, 20 M reads: 2^23)
+    assert suggest_part_bits(14, 20_000_000, 120) == 0
+    assert suggest_part_bits(14, 20_000_000, 120, min_bits=22) == 23
+    assert suggest_part_bits(14, 20_000_000, 120, min_bits=22, per_partition=1024) == 22   # what bench.py asks for at k <= 32
+    assert suggest_part_bits(14, 50_000_000, 120, min_bits=22, per_partition=1024) == 23
+    assert suggest_part_bits(14, 1000, 120, min_bits=22) == 22
+    assert suggest_part_bits(11, 20_000_000, 120, min_bits=22) == 0

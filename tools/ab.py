@@ -1,6 +1,6 @@
 """A/B timing of library variants: the same sources compiled with different -D flags, timed on the same workload.
     python tools/ab.py --build NAME[:-DFLAG[,-DFLAG...]] ...     (here: hipcc cross-compiles, variants in parallel)
-    python tools/ab.py --run K M B READS [NAME ...]                (GPU box: every built variant, or the named ones)
+    python tools/ab.py --run K M B READS [NAME ...]                (GPU box: every built variant, or the named ones; BRISK_AB_PART_BITS=N: brisk_hip_options.part_bits)
 Variants live in tests/_v/libbrisk_ab_<NAME>.so (git-ignored, travel with gpurun).  Each is timed in its own process
 (the library is loaded once per process): synthetic reads resident on the device, one warm-up job, then two timed jobs;
 prints the per-kernel HIP-event times of the last job, the index digest (equal digests <=> equal multisets: a variant
@@ -41,7 +41,7 @@ if "--one" in sys.argv:
     d_packed = torch.zeros((reads * 150 + 15) // 16 + 4, dtype=torch.int32, device=dev)
     d_starts = torch.zeros(reads + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()  # torch fills on its own stream, the library works on another: the fill must have landed
-    ix = brisk_amd.BriskHip(k, m, b)
+    ix = brisk_amd.BriskHip(k, m, b, part_bits=int(os.environ.get("BRISK_AB_PART_BITS", "0")))
     ix.synth_reads(max(reads * 10, 151), 0, reads, 150, d_packed.data_ptr(), d_starts.data_ptr())
     ix.sync()
     wall = 0.0
