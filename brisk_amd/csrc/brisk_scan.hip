@@ -472,10 +472,7 @@ struct ScanCfg {
 #define CLS_LO 12
 // NCH > 0: compile-time chunk count (unrolled look-ups); MM > 0: compile-time m, the whole layout folds into the instructions
 template <int NCH, int MM>
-__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg, const u64* tabs, const double* coef) {
-#ifdef SCAN_ATTR_NOCLASS  // attribution builds (tools/scan_attribution.py): wrong results, timing only
-    return (u32)x & 1u;
-#endif
+__device__ __forceinline__ u64 cls_sums(u64 x, const ScanCfg& cfg, const u64* tabs) {
     u64 acc;
     if (MM > 0) {
         constexpr u32 mm = MM > 0 ? (u32)MM : 1u;
@@ -496,9 +493,32 @@ __device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg,
             acc += tabs[(d >> 10) + ((u32)(x >> (d & 63)) & ((1u << ((d >> 6) & 15)) - 1))];
         }
     }
+    return acc;
+}
+template <int NCH, int MM>
+__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg, const u64* tabs, const double* coef) {
+#ifdef SCAN_ATTR_NOCLASS  // attribution builds (tools/scan_attribution.py): wrong results, timing only
+    return (u32)x & 1u;
+#endif
+    const u64 acc = cls_sums<NCH, MM>(x, cfg, tabs);
     const int a = (int)(u32)acc, b = (int)(u32)(acc >> 32) - (a >> 31);  // the high word holds B + floor(A / 2^32)
     const u32 ua = (u32)(a < 0 ? -a : a), ub = (u32)(b < 0 ? -b : b);
     if (ua - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2) || ub - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2)) return decy_class(x, m, coef);
+    const bool c0 = a >= CLS_HI && b <= CLS_LO, c1 = a <= -CLS_HI && b >= -CLS_LO;
+    return c0 ? 0u : c1 ? 1u : 2u;
+}
+// The same without a branch: a sum inside the guard band sets `guard` (the class returned is then not to be used) and the
+// caller repeats its work with the exact fold -- for loops that can be repeated (the (k-1)-mer's windows), so that nothing
+// inside them branches and the compiler can overlap two windows' look-ups.
+template <int NCH, int MM>
+__device__ __forceinline__ u32 decy_class_guarded(u64 x, const ScanCfg& cfg, const u64* tabs, bool& guard) {
+    const u64 acc = cls_sums<NCH, MM>(x, cfg, tabs);
+    const int a = (int)(u32)acc, b = (int)(u32)(acc >> 32) - (a >> 31);
+    const u32 ua = (u32)(a < 0 ? -a : a), ub = (u32)(b < 0 ? -b : b);
+    guard = guard | (ua - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2)) | (ub - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2));
+#ifdef CLS_FORCE_GUARD  // test builds: every pass is repeated with the exact fold (the path a guard-band sum takes once in a blue moon)
+    guard = true;
+#endif
     const bool c0 = a >= CLS_HI && b <= CLS_LO, c1 = a <= -CLS_HI && b >= -CLS_LO;
     return c0 ? 0u : c1 ? 1u : 2u;
 }
@@ -963,40 +983,92 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
 #ifndef SCAN_MINQUEUE
 #define SCAN_MINQUEUE 1   // 0: every expiry is re-scanned (A/B)
 #endif
+#ifndef PROLOGUE_UNROLL
+#define PROLOGUE_UNROLL 2
+#endif
+#define BRISK_PRAGMA_(x) _Pragma(#x)
+#define BRISK_PRAGMA(x) BRISK_PRAGMA_(x)
     const bool mq_on = SCAN_MINQUEUE && (KK ? (KK <= 32) : (k <= 32));  // wave-uniform: the window minimum from a per-lane queue (MinQueue) instead of re-scans
     MinQueue mq{MQ_EMPTY, MQ_EMPTY, MQ_EMPTY, 0u};
     {
         const u32 Km = k - 1 - m;
+        const u32 nwin = Km + 1 < nlow1 ? Km + 1 : nlow1;  // windows inside the low 64 bits; those that stick out of them are zero-padded (F2)
         u64 best = ~0ull;
         u32 first = 0, last = 0;
         bool rf = false, rl = false;
-        for (u32 ii = 0; ii <= Km; ii++) {
-            const u32 i = mq_on ? Km - ii : ii;  // (the queue takes the windows oldest first: window i of the (k-1)-mer is the candidate of step -1 - i)
-            u64 key;
-            bool rv;
-            if (i < nlow1) {  // inside the low 64 bits; windows that stick out of them are zero-padded (F2)
-                const u64 fwd = (low64 >> (2 * i)) & M;
-                const u64 rcv = rc64(fwd, m);
-                rv = rcv < fwd;
-                key = order_key_fast<NCH, MM>(rv ? rcv : fwd, m, M, cfg, s_tabs, s_coef);
-            } else {  // beyond the low 64 bits: the all-A m-mer
-                key = KEY0;
-                rv = false;
-            }
-            if (key < best) {
-                best = key;
-                first = last = i;
-                rf = rl = rv;
-            } else if (key == best) {
-                if (mq_on) {  // (descending i: an equal key lies at a smaller window index)
-                    first = i;
-                    rf = rv;
+        // One pass over the windows, every lane its own (k-1)-mer.  Nothing in the pass branches: a class sum inside the guard band
+        // (decy_class_guarded) only raises a flag, and the wave then repeats the pass with the exact fold (practically never).  Ascending
+        // windows roll: window i + 1 drops window i's last nucleotide and takes the next one of the low 64 bits (or an A) in front.
+        auto pass = [&](auto exact_tag) -> bool {
+            constexpr bool EXACT = decltype(exact_tag)::value;
+            best = ~0ull;
+            first = last = 0;
+            rf = rl = false;
+            bool guard = false;
+            u64 fw = low64 & M, rw = cr, above = low64 >> (2 * m);
+            if (mq_on) mq = MinQueue{MQ_EMPTY, MQ_EMPTY, MQ_EMPTY, 0u};
+#ifdef SCAN_ATTR_NOPROLOGUE  // attribution builds: wrong results, timing only
+            for (u32 ii = 0; ii < 1; ii++) {
+#else
+            BRISK_PRAGMA(unroll PROLOGUE_UNROLL)
+            for (u32 ii = 0; ii < nwin; ii++) {
+#endif
+                const u32 i = mq_on ? Km - ii : ii;  // (the queue takes the windows oldest first: window i of the (k-1)-mer is the candidate of step -1 - i)
+                u64 fwd, rcv;
+                if (mq_on) {
+                    fwd = (low64 >> (2 * i)) & M;
+                    rcv = rc64(fwd, m);
                 } else {
-                    last = i;
-                    rl = rv;
+                    fwd = fw;
+                    rcv = rw;
+                    const u32 t = (u32)above & 3u;
+                    above >>= 2;
+                    fw = (fw >> 2) | ((u64)t << (2 * m - 2));
+                    rw = ((rw << 2) & M) | (t ^ 2u);
                 }
+                const bool rv = rcv < fwd;
+                const u64 x = rv ? rcv : fwd;
+                u64 key;
+                if (EXACT) key = order_key(x, m, M, s_coef);
+                else {
+#ifdef SCAN_ATTR_NOCLASS
+                    key = order_key_fast<NCH, MM>(x, m, M, cfg, s_tabs, s_coef);
+#else
+                    key = ((u64)decy_class_guarded<NCH, MM>(x, cfg, s_tabs, guard) << 62) + mix2m(x, M);
+#endif
+                }
+                if (key < best) {
+                    best = key;
+                    first = last = i;
+                    rf = rl = rv;
+                } else if (key == best) {
+                    if (mq_on) {  // (descending i: an equal key lies at a smaller window index)
+                        first = i;
+                        rf = rv;
+                    } else {
+                        last = i;
+                        rl = rv;
+                    }
+                }
+                if (mq_on) mq_push(mq, key, 0u - 1u - i, rv);
             }
-            if (mq_on) mq_push(mq, key, 0u - 1u - i, rv);
+            return guard;
+        };
+#ifdef SCAN_ATTR_PROLOGUE_TWICE  // attribution builds: the pass' cost, results unchanged
+        if (__ballot(pass(std::false_type{})) == 0x123456789ull) return;
+        __builtin_amdgcn_s_barrier();
+#endif
+        if (__ballot(pass(std::false_type{}))) pass(std::true_type{});
+        if (Km >= nwin) {  // windows nlow1..Km of a (k-1)-mer longer than 32: the all-A m-mer (k - 1 > 32 only: never with the queue)
+            if (KEY0 < best) {
+                best = KEY0;
+                first = nwin;
+                last = Km;
+                rf = rl = false;
+            } else if (KEY0 == best) {
+                last = Km;
+                rl = false;
+            }
         }
         u32 pos;
         bool rev, need_canon;
@@ -1092,8 +1164,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
                 served = true;
             }
         }
-        SCNT(6, (u32)__popcll(__ballot(served)))
         unsigned long long need = __ballot(expired && !dead && !served);
+        SCNT(6, (u32)__popcll(__ballot(served)))
         SCNT(1, (u32)__popcll(need))
 #ifdef SCAN_ATTR_NORESCAN
         if (expired) {
@@ -1142,6 +1214,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
                 }
                 tie = __ballot(key == hm);
             }
+#ifdef SCAN_ATTR_RS_NOEPI  // attribution builds: wrong results, timing only
+            if ((int)lane == LA || (two && (int)lane == LB)) {
+                mini_hash = key;
+                mini_pos = (u32)tie & 31u;
+                reversed = rv;
+            }
+            if (false)
+#endif
             for (int half = 0; half < (two ? 2 : 1); half++) {  // wave-uniform, scalar work
                 const int L = half ? LB : LA;
                 const u32 t = (u32)(tie >> (32 * half)), rb = (u32)(rvb >> (32 * half));

@@ -5,7 +5,9 @@ mixer).    python tools/scan_attribution.py --build     (here)      python tools
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {"full": [], "norescan": ["-DSCAN_ATTR_NORESCAN"], "noemit": ["-DSCAN_ATTR_NOEMIT"], "noclass": ["-DSCAN_ATTR_NOCLASS"], "nomix": ["-DSCAN_ATTR_NOMIX"],
-            "nokey": ["-DSCAN_ATTR_NOCLASS", "-DSCAN_ATTR_NOMIX"], "norescan_noemit": ["-DSCAN_ATTR_NORESCAN", "-DSCAN_ATTR_NOEMIT"]}
+            "nokey": ["-DSCAN_ATTR_NOCLASS", "-DSCAN_ATTR_NOMIX"], "norescan_noemit": ["-DSCAN_ATTR_NORESCAN", "-DSCAN_ATTR_NOEMIT"],
+            # the (k-1)-mer's windows run twice (same records: the pass' cost); the re-scan's scalar tie resolution left out (wrong records)
+            "prologue_twice": ["-DSCAN_ATTR_PROLOGUE_TWICE"], "rescan_noepilogue_noemit": ["-DSCAN_ATTR_RS_NOEPI", "-DSCAN_ATTR_NOEMIT"]}
 vdir = os.path.join(ROOT, "tests", "_v")
 if "--build" in sys.argv:
     os.makedirs(vdir, exist_ok=True)
