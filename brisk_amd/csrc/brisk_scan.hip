@@ -495,21 +495,9 @@ __device__ __forceinline__ u64 cls_sums(u64 x, const ScanCfg& cfg, const u64* ta
     }
     return acc;
 }
-template <int NCH, int MM>
-__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg, const u64* tabs, const double* coef) {
-#ifdef SCAN_ATTR_NOCLASS  // attribution builds (tools/scan_attribution.py): wrong results, timing only
-    return (u32)x & 1u;
-#endif
-    const u64 acc = cls_sums<NCH, MM>(x, cfg, tabs);
-    const int a = (int)(u32)acc, b = (int)(u32)(acc >> 32) - (a >> 31);  // the high word holds B + floor(A / 2^32)
-    const u32 ua = (u32)(a < 0 ? -a : a), ub = (u32)(b < 0 ? -b : b);
-    if (ua - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2) || ub - (CLS_LO + 1) <= (u32)(CLS_HI - CLS_LO - 2)) return decy_class(x, m, coef);
-    const bool c0 = a >= CLS_HI && b <= CLS_LO, c1 = a <= -CLS_HI && b >= -CLS_LO;
-    return c0 ? 0u : c1 ? 1u : 2u;
-}
-// The same without a branch: a sum inside the guard band sets `guard` (the class returned is then not to be used) and the
-// caller repeats its work with the exact fold -- for loops that can be repeated (the (k-1)-mer's windows), so that nothing
-// inside them branches and the compiler can overlap two windows' look-ups.
+// A sum inside the guard band sets `guard` (the class returned is then not to be used) and the caller goes to the exact fold: a
+// lone key behind one wave-uniform branch (decy_class_fast), a loop that can be repeated (the (k-1)-mer's windows) as a whole, so
+// that nothing inside it branches.
 template <int NCH, int MM>
 __device__ __forceinline__ u32 decy_class_guarded(u64 x, const ScanCfg& cfg, const u64* tabs, bool& guard) {
     const u64 acc = cls_sums<NCH, MM>(x, cfg, tabs);
@@ -521,6 +509,18 @@ __device__ __forceinline__ u32 decy_class_guarded(u64 x, const ScanCfg& cfg, con
 #endif
     const bool c0 = a >= CLS_HI && b <= CLS_LO, c1 = a <= -CLS_HI && b >= -CLS_LO;
     return c0 ? 0u : c1 ? 1u : 2u;
+}
+template <int NCH, int MM>
+__device__ __forceinline__ u32 decy_class_fast(u64 x, u32 m, const ScanCfg& cfg, const u64* tabs, const double* coef) {
+#ifdef SCAN_ATTR_NOCLASS  // attribution builds (tools/scan_attribution.py): wrong results, timing only
+    return (u32)x & 1u;
+#endif
+    bool guard = false;
+    u32 cls = decy_class_guarded<NCH, MM>(x, cfg, tabs, guard);
+    if (__ballot(guard)) {  // wave-uniform and practically never taken: no lane-level branch on the way of the others
+        if (guard) cls = decy_class(x, m, coef);
+    }
+    return cls;
 }
 template <int NCH = 0, int MM = 0>
 __device__ __forceinline__ u64 order_key_fast(u64 x, u32 m, u64 M, const ScanCfg& cfg, const u64* tabs, const double* coef) {
