@@ -993,17 +993,18 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
     {
         const u32 Km = k - 1 - m;
         const u32 nwin = Km + 1 < nlow1 ? Km + 1 : nlow1;  // windows inside the low 64 bits; those that stick out of them are zero-padded (F2)
-        u64 best = ~0ull;
-        u32 first = 0, last = 0;
-        bool rf = false, rl = false;
         // One pass over the windows, every lane its own (k-1)-mer.  Nothing in the pass branches: a class sum inside the guard band
         // (decy_class_guarded) only raises a flag, and the wave then repeats the pass with the exact fold (practically never).  Ascending
         // windows roll: window i + 1 drops window i's last nucleotide and takes the next one of the low 64 bits (or an A) in front.
-        auto pass = [&](auto exact_tag) -> bool {
+        // (Everything the pass works on is local to it and returned by value: flags captured by reference ended up in scratch.)
+        struct WinMin {
+            u64 best;
+            u32 first, last, flags;  // flags: reversed at first | reversed at last << 1 | a sum in the guard band << 2
+        };
+        auto pass = [&](auto exact_tag) -> WinMin {
             constexpr bool EXACT = decltype(exact_tag)::value;
-            best = ~0ull;
-            first = last = 0;
-            rf = rl = false;
+            u64 best = ~0ull;
+            u32 first = 0, last = 0, rf = 0, rl = 0;
             bool guard = false;
             u64 fw = low64 & M, rw = cr, above = low64 >> (2 * m);
             if (mq_on) mq = MinQueue{MQ_EMPTY, MQ_EMPTY, MQ_EMPTY, 0u};
@@ -1037,28 +1038,32 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(scan_
                     key = ((u64)decy_class_guarded<NCH, MM>(x, cfg, s_tabs, guard) << 62) + mix2m(x, M);
 #endif
                 }
-                if (key < best) {
-                    best = key;
-                    first = last = i;
-                    rf = rl = rv;
-                } else if (key == best) {
-                    if (mq_on) {  // (descending i: an equal key lies at a smaller window index)
-                        first = i;
-                        rf = rv;
-                    } else {
-                        last = i;
-                        rl = rv;
-                    }
+                const bool lt = key < best, eq = key == best;
+                best = lt ? key : best;
+                if (mq_on) {  // (descending i: an equal key lies at a smaller window index)
+                    first = lt || eq ? i : first;
+                    rf = lt || eq ? (u32)rv : rf;
+                    last = lt ? i : last;
+                    rl = lt ? (u32)rv : rl;
+                } else {
+                    first = lt ? i : first;
+                    rf = lt ? (u32)rv : rf;
+                    last = lt || eq ? i : last;
+                    rl = lt || eq ? (u32)rv : rl;
                 }
                 if (mq_on) mq_push(mq, key, 0u - 1u - i, rv);
             }
-            return guard;
+            return WinMin{best, first, last, rf | (rl << 1) | (guard ? 4u : 0u)};
         };
 #ifdef SCAN_ATTR_PROLOGUE_TWICE  // attribution builds: the pass' cost, results unchanged
-        if (__ballot(pass(std::false_type{})) == 0x123456789ull) return;
+        if (__ballot(pass(std::false_type{}).flags & 4u) == 0x123456789ull) return;
         __builtin_amdgcn_s_barrier();
 #endif
-        if (__ballot(pass(std::false_type{}))) pass(std::true_type{});
+        WinMin wm = pass(std::false_type{});
+        if (__ballot(wm.flags & 4u)) wm = pass(std::true_type{});
+        u64 best = wm.best;
+        u32 first = wm.first, last = wm.last;
+        bool rf = wm.flags & 1u, rl = wm.flags & 2u;
         if (Km >= nwin) {  // windows nlow1..Km of a (k-1)-mer longer than 32: the all-A m-mer (k - 1 > 32 only: never with the queue)
             if (KEY0 < best) {
                 best = KEY0;
