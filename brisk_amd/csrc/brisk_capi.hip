@@ -19,6 +19,11 @@
 
 #include "../../include/brisk_hip.h"
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
+#define BRISK_HOST_AVX2 1
+#endif
+
 namespace {
 
 enum Slot { S_PACK, S_SYNTH, S_COUNT, S_SCAN, S_HIST, S_PSUM, S_TOUCHED, S_SCATTER, S_INSERT, S_QUERY, S_ENUM, S_LOOKUP, S_UPLOAD, S_NSLOTS };
@@ -1158,10 +1163,52 @@ int query_records_impl(brisk_hip_index* h, const u64* d_rec, const u32* d_tags, 
     return launch_check(h, "k_query_huge");
 }
 
+// nuc2int (Kmers.cpp:442-444) in bulk on the host: n ASCII bytes -> (n + 15) / 16 words of the packed stream, first nucleotide of a
+// word in its top bits, the last word zero padded (the layout k_pack_ascii writes).  The format conversion at the boundary -- the
+// upload threads do it in the pass over the caller's bytes that stages them into pinned memory, so that a quarter of the bytes
+// cross PCIe -- not part of the path's arithmetic: everything from the packed stream on is device code.
+static void host_pack_scalar(const char* s, u64 n, u32* out) {
+    const u64 n_words = (n + 15) / 16;
+    for (u64 w = 0; w < n_words; w++) {
+        const u64 left = n - w * 16;
+        u32 v = 0;
+        for (u64 i = 0; i < 16; i++) v = (v << 2) | (i < left ? (((uint8_t)s[w * 16 + i] >> 1) & 3u) : 0u);
+        out[w] = v;
+    }
+}
+#ifdef BRISK_HOST_AVX2
+__attribute__((target("avx2"))) static void host_pack_avx2(const char* s, u64 n, u32* out) {
+    const u64 n32 = n / 32;  // 32 bytes -> two words
+    const __m256i three = _mm256_set1_epi8(3);
+    const __m256i mul41 = _mm256_set1_epi16(0x0104);      // bytes (4, 1): n0 * 4 + n1 per byte pair
+    const __m256i mul161 = _mm256_set1_epi32(0x00010010);  // 16-bit (16, 1): t0 * 16 + t1 = the byte of four nucleotides
+    const __m256i pick = _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    for (u64 i = 0; i < n32; i++) {
+        __m256i v = _mm256_loadu_si256((const __m256i*)(s + 32 * i));
+        v = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);
+        const __m256i t = _mm256_maddubs_epi16(v, mul41);
+        const __m256i b = _mm256_madd_epi16(t, mul161);
+        const __m256i w = _mm256_shuffle_epi8(b, pick);
+        out[2 * i] = (u32)_mm256_extract_epi32(w, 0);
+        out[2 * i + 1] = (u32)_mm256_extract_epi32(w, 4);
+    }
+    if (n32 * 32 < n) host_pack_scalar(s + n32 * 32, n - n32 * 32, out + 2 * n32);
+}
+#endif
+static void host_pack(const char* s, u64 n, u32* out) {
+#ifdef BRISK_HOST_AVX2
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return host_pack_avx2(s, n, out);
+#endif
+    host_pack_scalar(s, n, out);
+}
+
 // Host ASCII -> packed 2-bit stream on the device.  The caller's memory is pageable: a plain hipMemcpy moves it at
-// 17-19 GB/s through the runtime's single staging path.  Here a few host threads copy chunks into their own pinned
-// buffers (two each, so a thread fills one while the copy engine drains the other) and pack every chunk where it
-// lands; chunks are whole 16-nt words of the packed stream, so they are independent.  Process-wide, one upload at a time.
+// 17-19 GB/s through the runtime's single staging path.  Here a few host threads take chunks into their own pinned
+// buffers (two each, so a thread fills one while the copy engine drains the other); chunks are whole 16-nt words of the
+// packed stream, so they are independent.  [r3] The threads pack while they stage (host_pack: the pass over the caller's
+// bytes that used to be a memcpy) and the copy engine moves the packed words straight to their place; BRISK_HOST_PACK=0
+// keeps the older route (ASCII over PCIe, k_pack_ascii where it lands).  Process-wide, one upload at a time.
 struct UploadLane {
     hipStream_t st = nullptr;
     char* pin[2] = {nullptr, nullptr};
@@ -1169,7 +1216,16 @@ struct UploadLane {
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 constexpr size_t kUploadChunk = (size_t)16 << 20;
-constexpr unsigned kUploadLanes = 6;
+static unsigned upload_lanes() {  // BRISK_UPLOAD_LANES: host threads of an upload (default 12 packing, 6 on the older route: more only fought over PCIe there)
+    static const unsigned n = [] {
+        const char* e = getenv("BRISK_UPLOAD_LANES");
+        const long v = e ? atol(e) : 0;
+        const bool hp = !(getenv("BRISK_HOST_PACK") && atoi(getenv("BRISK_HOST_PACK")) == 0);
+        return (unsigned)(v >= 1 && v <= 64 ? v : hp ? 12 : 6);
+    }();
+    return n;
+}
+#define kUploadLanes upload_lanes()
 std::mutex g_upload_mu;
 std::vector<UploadLane> g_upload;
 int g_upload_device = -1;
@@ -1178,6 +1234,7 @@ int g_upload_device = -1;
 // stream belongs to the caller's thread -- only the lanes' streams are touched here, and an error text goes to *err_out, not h->err.
 int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, u64 n_words, bool pipelined = false, std::string* err_out = nullptr) {
     const u64 n_chunks = (nb + kUploadChunk - 1) / kUploadChunk;
+    static const bool host_packs = !(getenv("BRISK_HOST_PACK") && atoi(getenv("BRISK_HOST_PACK")) == 0);
     auto in_one_piece = [&]() -> int {  // plain copy of the whole input, then one pack launch
         int rc;
         if ((rc = ensure(h, h->bases_tmp, nb + 16))) return rc;
@@ -1205,8 +1262,8 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
         for (UploadLane& l : g_upload) {
             ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess;
             for (int i = 0; i < 2 && ok; i++)
-                ok = hipHostMalloc((void**)&l.pin[i], kUploadChunk) == hipSuccess && hipMalloc((void**)&l.dev[i], kUploadChunk) == hipSuccess &&
-                     hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming) == hipSuccess;
+                ok = hipHostMalloc((void**)&l.pin[i], host_packs ? kUploadChunk / 4 : kUploadChunk) == hipSuccess &&
+                     (host_packs || hipMalloc((void**)&l.dev[i], kUploadChunk) == hipSuccess) && hipEventCreateWithFlags(&l.ev[i], hipEventDisableTiming) == hipSuccess;
         }
         if (!ok) {  // no room for the pinned lanes (192 MiB of host, as much of device memory): the plain path still works
             (void)hipGetLastError();
@@ -1230,11 +1287,17 @@ int upload_and_pack(brisk_hip_index* h, const char* src, u64 nb, u32* d_packed, 
                 const u64 off = c * kUploadChunk, len = std::min<u64>(kUploadChunk, nb - off);
                 e = hipEventSynchronize(l.ev[turn]);  // the copy that used this buffer two chunks ago has drained it
                 if (e != hipSuccess) break;
-                memcpy(l.pin[turn], src + off, len);
-                e = hipMemcpyAsync(l.dev[turn], l.pin[turn], len, hipMemcpyHostToDevice, l.st);
-                if (e != hipSuccess) break;
                 const u64 words = (len + 15) / 16;
-                hipLaunchKernelGGL(k_pack_ascii, dim3(nblocks(words, 256)), dim3(256), 0, l.st, (const uint8_t*)l.dev[turn], len, d_packed + off / 16, words);
+                if (host_packs) {
+                    host_pack(src + off, len, (u32*)l.pin[turn]);
+                    e = hipMemcpyAsync(d_packed + off / 16, l.pin[turn], words * 4, hipMemcpyHostToDevice, l.st);
+                    if (e != hipSuccess) break;
+                } else {
+                    memcpy(l.pin[turn], src + off, len);
+                    e = hipMemcpyAsync(l.dev[turn], l.pin[turn], len, hipMemcpyHostToDevice, l.st);
+                    if (e != hipSuccess) break;
+                    hipLaunchKernelGGL(k_pack_ascii, dim3(nblocks(words, 256)), dim3(256), 0, l.st, (const uint8_t*)l.dev[turn], len, d_packed + off / 16, words);
+                }
                 e = hipEventRecord(l.ev[turn], l.st);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(l.st);
@@ -1382,7 +1445,11 @@ int insert_reads_pipelined(brisk_hip_index* h, const char* bases, const uint64_t
         u64 r0, r1;
     };
     std::vector<Sub> subs;
-    const u64 want = kPipeChunks * kUploadChunk;
+    // pieces of at least kPipeChunks chunks, and no more than about eight of them: every piece pays the path's fixed costs (a dozen
+    // launches and host synchronisations), and large pieces take the binned scan.  BRISK_PIPE_PIECES overrides the eight.
+    static const u64 n_pieces = getenv("BRISK_PIPE_PIECES") && atol(getenv("BRISK_PIPE_PIECES")) > 0 ? (u64)atol(getenv("BRISK_PIPE_PIECES")) : 8;
+    const u64 total = offsets[n_reads] - offsets[0];
+    const u64 want = std::max<u64>(kPipeChunks * kUploadChunk, (total / n_pieces + kUploadChunk - 1) / kUploadChunk * kUploadChunk);
     for (u64 r0 = 0; r0 < n_reads;) {
         u64 r1 = (u64)(std::upper_bound(offsets + r0, offsets + n_reads + 1, offsets[r0] + want) - offsets) - 1;
         if (r1 <= r0) r1 = r0 + 1;
@@ -2543,6 +2610,12 @@ BRISK_API int brisk_hip_debug_order_keys(brisk_hip_index* h, const uint64_t* mme
     return BRISK_HIP_OK;
 }
 
+BRISK_API int brisk_hip_debug_host_pack(const char* bases, uint64_t n_bases, uint32_t* packed, int scalar) {  // the upload threads' packer, for tests (no device)
+    if (n_bases && (!bases || !packed)) return BRISK_HIP_EINVAL;
+    if (scalar) host_pack_scalar(bases, n_bases, packed);
+    else host_pack(bases, n_bases, packed);
+    return BRISK_HIP_OK;
+}
 #ifdef BRISK_PHASE_PROF
 BRISK_API int brisk_hip_debug_scan_counts(uint64_t out[8], int reset) {  // debug builds only (tools/phase_profile.py)
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_cnt), 8 * 8) != hipSuccess) return BRISK_HIP_EHIP;
