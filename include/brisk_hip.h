@@ -106,7 +106,10 @@ typedef struct brisk_hip_options {
     uint32_t part_bits;         /* log2(#partitions), at most 2b; 0: default (2^24, also when 2b < 24: see brisk_hip_layout.ext_bits).
                                  * The insert is at its best with 10-20 records (a few hundred k-mer instances) per partition
                                  * and call: 2^24 suits batches of 50 M reads on one index; a sharded job whose owners each
-                                 * receive that much (N x 50 M reads per batch over N owners) wants 24 + log2(N) */
+                                 * receive that much (N x 50 M reads per batch over N owners) wants 24 + log2(N); a job of ONE
+                                 * smaller batch of short k-mers wants fewer (k31 m15 b14, 20 M reads: 2^22 -- two-word records of
+                                 * nine k-mers leave 2^24 partitions with a dozen entries each; the k63 insert loses with fewer
+                                 * than 2^24).  brisk_amd.exchange.suggest_part_bits states the rule bench.py uses */
     uint32_t owner_rank;        /* this process' rank among n_owners bucket-range owners */
     uint32_t n_owners;          /* 0 or 1: this index owns every bucket; at most 256 (else EUNSUPPORTED) */
     uint64_t arena_entries;     /* initial entry capacity of the k-mer arena; 0: grow on demand */
@@ -155,7 +158,11 @@ int brisk_hip_get_layout(const brisk_hip_index *h, brisk_hip_layout *out);
 /* ---- bulk count (DATA = uint8_t counter: first touch = 1, then ++ mod 256) -- */
 /* HOST buffers: `bases` = concatenated sequences, `offsets[n_reads+1]`.  Sequences
  * must be clean ([ACGTacgt]; the N-splitting of counter.cpp:130-169 is the caller's);
- * sequences shorter than k are skipped (counter.cpp:233-235). */
+ * sequences shorter than k are skipped (counter.cpp:233-235).  A large batch is taken in
+ * pieces: a dozen host threads turn the bytes into the 2-bit stream (nuc2int, Kmers.cpp:442-444)
+ * while they stage them into pinned memory, and the scan of one piece runs under the upload of
+ * the next (environment: BRISK_UPLOAD_LANES, BRISK_PIPE_PIECES, BRISK_UPLOAD_PIPELINE=0,
+ * BRISK_HOST_PACK=0 for ASCII over PCIe and k_pack_ascii on arrival). */
 int brisk_hip_insert_reads(brisk_hip_index *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 
 /* DEVICE buffers: 2-bit packed stream (16 nts per u32, first nt in the top bits;
