@@ -104,3 +104,28 @@ def test_batches_of_one_line_records_end_between_records(dumper, tmp_path):
         assert [l for l in lines if not l.startswith("#")] == reads
         assert sum(sizes) == len(reads) and len(sizes) >= 15, sizes  # 60 kb in batches of >= 3 kb: 20 whole reads each
         assert max(sizes) <= 40, sizes
+
+
+def test_clean_ranges_are_copied_in_place_and_dirty_ones_parsed(dumper, tmp_path):
+    """Mapped files take two passes per batch: a thread's run of records is counted first and, if every sequence line holds
+    [ACGTacgt] only, copied straight to its place in the batch (upper-cased, one sequence per record); a run with anything
+    else goes through the general parser.  Clean multi-line records with lower case and empty records, no trailing newline;
+    then the same file with one dirty stretch in the middle, so that some threads' runs are clean and others are not."""
+    rng = random.Random(33)
+
+    def rec(i, alphabet, n):
+        body = "".join(rng.choice(alphabet) for _ in range(n))
+        lines = [body[j:j + 61] for j in range(0, len(body), 61)]
+        return ">c%d\n" % i + "\n".join(lines)
+
+    clean = [rec(i, "ACGTacgt", rng.choice([0, 1, 31, 32, 33, 64, 150, 1000])) for i in range(600)]
+    dirty = [rec(i, "ACGTNn-", rng.randint(1, 300)) for i in range(40)]
+    for name, recs in (("clean.fa", clean), ("mixed.fa", clean[:300] + dirty + clean[300:])):
+        text = "\n".join(recs)  # no trailing newline
+        p = str(tmp_path / name)
+        open(p, "w").write(text)
+        want = oracle.fasta_sequences(text)
+        assert want and all(s == s.upper() for s in want)
+        for batch in (500, 20000, 1 << 20):
+            for threads in (1, 3, 8):
+                assert run(dumper, p, batch, threads) == want, (name, batch, threads)
