@@ -327,6 +327,10 @@ class FastaReader {
         size_t o = out.flat.size();
         out.flat.resize(o + (size_t)(stop - p));
         char* d = &out.flat[0];
+        if (all_bases(p, stop)) {  // the common line: nothing but bases, copied (upper-cased) 32 bytes at a time
+            copy_upper(d + o, p, (size_t)(stop - p));
+            return;
+        }
         for (; p < stop; p++) {
             const unsigned char u = tab.t[(unsigned char)*p];
             if (u) {
