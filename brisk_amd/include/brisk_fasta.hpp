@@ -108,9 +108,7 @@ class FastaBytes {
     size_t n_ = 0, cap_ = 0;
     bool mapped_ = false;
 };
-namespace std {
-inline void swap(FastaBytes& a, FastaBytes& b) noexcept { a.swap(b); }
-}  // namespace std
+inline void swap(FastaBytes& a, FastaBytes& b) noexcept { a.swap(b); }  // (found by argument-dependent lookup; std::swap works too, through the moves)
 
 struct FastaBatch {
     FastaBytes flat;             // concatenated sequences
