@@ -386,7 +386,7 @@ def end_to_end(k, m, b, L, n_reads, d_packed):
     for name, path in (("fa_gz", gz), ("fa", fa)):
         best = None
         for rep in range(2):  # (the first run pays the arena mapping and the page cache)
-            r = subprocess.run([exe, "--bulk", path, str(k), str(m), str(b), "-"], capture_output=True, text=True, timeout=900, env=dict(os.environ, BRISK_E2E_JSON="1"))
+            r = subprocess.run([exe, "--bulk", path, str(k), str(m), str(b), "-"], capture_output=True, text=True, timeout=max(180, n_reads // 50_000), env=dict(os.environ, BRISK_E2E_JSON="1"))  # (the leg runs before the timed steps: it must not be able to hold them up)
             if r.returncode != 0:
                 raise RuntimeError("brisk_count failed: " + r.stderr[-300:])
             d = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("E2E "))[4:])
